@@ -1,0 +1,601 @@
+"""CPU oracle: a numpy restatement of gmweir/PYFFT's spectral hot path.
+
+*** TEST INFRASTRUCTURE -- NOT PRODUCT CODE. ***
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module, and only as the checker.  pyfft_amd/ never imports it.
+
+Every function cites the reference file:line it follows (paths are relative to
+the reference checkout).  Arithmetic is float64/complex128 exactly where the
+reference's is (SURVEY.md quirks Q1-Q6 are reproduced, not "fixed").
+
+Pinning: tests/test_oracle_golden.py checks every function here against the
+fixtures in tests/golden/*.npz, which were produced by running the reference's
+own modules (tests/golden/make_golden.py), plus the reference's known-answer
+material (hilbert.py:115-140 analytic identity, notch_filter.py:66-71, Heinzel
+window constants echoed at windows.py:68-269).
+Unpinned boundary: pybaseutils.utils.detrend_* is absent from the reference
+checkout; mean / least-squares-line removal along axis 0 is assumed (the
+matplotlib.mlab semantics) -- "parity unpinned" at that one call.
+"""
+import numpy as np
+
+# --------------------------------------------------------------------------- #
+# A1  windows.windows()                                    windows.py:57-297
+# --------------------------------------------------------------------------- #
+_COS_SUM = [  # (substring, coefficients, ROV)  -- order matters: windows.py:101-217 tests substrings in this order
+    ("3f", (0.26526, -0.5, 0.23474), 0.667),
+    ("4f", (0.21706, -0.42103, 0.28294, -0.07897), 0.75),
+    ("5f", (0.1881, -0.36923, 0.28702, -0.13077, 0.02488), 0.785),
+    ("3m", (0.28235, -0.52105, 0.19659), 0.655),
+    ("4m", (0.241906, -0.460841, 0.255381, -0.041872), 0.721),
+    ("5m", (0.209671, -0.407331, 0.281225, -0.092669, 0.0091036), 0.760),
+    ("3a", (0.40897, -0.5, 0.09103), 0.612),
+    ("3b", (0.4243801, -0.4973406, 0.0782793), 0.598),
+    ("3", (0.375, -0.5, 0.125), 0.647),
+    ("4a", (0.338946, -0.481973, 0.161054, -0.018027), 0.68),
+    ("4b", (0.355768, -0.487396, 0.144232, -0.012604), 0.663),
+    ("4c", (0.3635819, -0.4891775, 0.1365995, -0.0106411), 0.656),
+    ("4", (0.3125, -0.46875, 0.1875, -0.03125), 0.705),
+]
+
+
+def _cos_sum(cc):
+    def func(n):
+        # windows.py:222-232 -- note the divisor is the *requested* length, so the
+        # "periodic" variant (func(N+1)[:-1]) samples z = 2 pi k/(N+1)
+        z = 2.0 * np.pi * np.arange(n) / n
+        w = np.zeros(n, dtype=np.float64)
+        for i, ci in enumerate(cc):
+            w += ci if i == 0 else ci * np.cos(i * z)
+        return w
+    return func
+
+
+def _window_func(name, beta=None):
+    """(func(n) -> symmetric-or-whatever window of length n, ROV).  windows.py:63-272"""
+    s = name.lower()
+    if "hann" in s:
+        return np.hanning, 0.50
+    if "hamm" in s:
+        return np.hamming, 0.50
+    if "black" in s:
+        return _cos_sum((0.35875, -0.48829, 0.14128, -0.01168)), 0.661     # windows.py:92-96
+    if "nut" in s or "flat" in s or "sft" in s:
+        for sub, cc, rov in _COS_SUM:
+            if sub in s:
+                return _cos_sum(cc), rov
+        raise NameError("windows(): no coefficient set selected for %r (reference raises too)" % name)
+    if "kaiser" in s:
+        if beta is None:
+            raise KeyError("beta")
+        return (lambda n: np.kaiser(n, beta)), 2.0 / 3.0
+    if "welch" in s:
+        def func(n):                                                         # windows.py:249-252
+            z = 2.0 * np.arange(n) / n
+            return 1.0 - (z - 1.0) * (z - 1.0)
+        return func, 0.293
+    if "bart" in s:
+        return np.bartlett, 0.50
+    return (lambda n: np.ones(n, dtype=np.float64)), 0.0                     # windows.py:264-271
+
+
+def windows(windowfunction, nwins=None, periodic=True, beta=None):
+    """windows.py:57-297.  Without nwins: the recommended overlap (ROV)."""
+    func, rov = _window_func(windowfunction, beta)
+    if nwins is None:
+        return rov
+    if periodic:
+        return func(nwins + 1)[:-1]          # windows.py:276-279
+    return func(nwins)
+
+
+# --------------------------------------------------------------------------- #
+# A2  segment geometry and normalisation            fft_analysis.py:2412-2510
+# --------------------------------------------------------------------------- #
+def get_nwins(nsig, Navr, ov):               # :2412-2418
+    nwins = int(np.floor(nsig * 1.0 / (Navr - Navr * ov + ov)))
+    return nsig if nwins >= nsig else nwins
+
+
+def get_noverlap(nwins, ov):                 # :2421-2422
+    return int(np.ceil(ov * nwins))
+
+
+def get_navr(nsig, nwins, noverlap):         # :2425-2429
+    return 1 if nwins >= nsig else (nsig - noverlap) // (nwins - noverlap)
+
+
+def get_nnyquist(nfft):                      # :2471-2484
+    return (nfft + 1) // 2 if nfft % 2 else nfft // 2
+
+
+def get_norms(win, Nnyquist, Fs):            # :2487-2510  (Q3: NENBW uses Nnyquist)
+    S1 = np.sum(win)
+    S2 = np.sum(win ** 2.0)
+    return S1, S2, Nnyquist * 1.0 * S2 / (S1 ** 2), Fs * S2 / (S1 ** 2)
+
+
+def get_fs(tvec):                            # :2376-2377
+    return (len(tvec) - 1) / (tvec[-1] - tvec[0])
+
+
+def get_ibounds(tvec, tbounds):              # :2380-2383
+    Fs = get_fs(tvec)
+    return [int(np.floor((tbounds[0] - tvec[0]) * Fs)), int(np.floor(1 + (tbounds[1] - tvec[0]) * Fs))]
+
+
+# --------------------------------------------------------------------------- #
+# A13  detrend                      pybaseutils.utils (absent) -- parity unpinned
+# --------------------------------------------------------------------------- #
+def detrend(x, style):
+    """style >0 mean, 0 none, <0 linear; along axis 0  (fft_analysis.py:2539-2549)"""
+    x = np.asarray(x)
+    if style is None or style == 0:
+        return x
+    if style > 0:
+        return x - x.mean(axis=0, keepdims=True)      # stays in the input dtype (Q6)
+    n = x.shape[0]
+    k = np.arange(n, dtype=np.float64)
+    A = np.stack([k, np.ones(n)], axis=1)
+    coef = np.linalg.lstsq(A, x.reshape(n, -1), rcond=None)[0]
+    return x - (A @ coef).reshape(x.shape)
+
+
+# --------------------------------------------------------------------------- #
+# A3  fftanal.fft_win                                fft_analysis.py:2126-2203
+# --------------------------------------------------------------------------- #
+def fft_win(sig, tvec, win, nwins, noverlap, Navr, onesided, S1, S2, ENBW, detrend_style=1):
+    """Returns (tt, freq, Xfft[Navr, nfft or Nnyquist] complex128, pseg[Navr])."""
+    x_in = detrend(np.array(sig, copy=True), detrend_style)      # :2127, :2148 global detrend
+    Fs = get_fs(tvec)
+    nfft = nwins
+    Nny = get_nnyquist(nfft)
+    hop = nwins - noverlap
+    Xfft = np.zeros((Navr, nfft), dtype=np.complex128)
+    tt = np.zeros(Navr)
+    pseg = np.zeros(Navr)
+    for g in range(Navr):                                       # :2156-2176
+        i0 = g * hop
+        seg = win * x_in[i0:i0 + nwins]
+        tt[g] = np.mean(tvec[i0:i0 + nwins])
+        pseg[g] = np.trapezoid(seg * np.conj(seg), x=tvec[i0:i0 + nwins]).real
+        Xfft[g] = np.fft.fft(seg, n=nfft)
+    freq = np.fft.fftfreq(nfft, 1.0 / Fs)
+    if onesided:                                                # :2179-2189  (Q1)
+        freq = freq[:Nny]
+        Xfft = Xfft[:, :Nny]
+        Xfft[:, 1:-1] = np.sqrt(2) * Xfft[:, 1:-1]
+        if nfft % 2:
+            Xfft[:, -1] = np.sqrt(2) * Xfft[:, -1]
+    else:                                                       # :2191-2192
+        freq = np.fft.fftshift(freq)
+        Xfft = np.fft.fftshift(Xfft, axes=-1)
+    Xfft = Xfft / S1                                            # :2197
+    pseg = pseg / S2                                            # :2198
+    Xfft = Xfft / np.sqrt(ENBW)                                 # :2202
+    return tt, freq, Xfft, pseg
+
+
+def class_setup(tvec, sigx, Navr=None, windowfunction="Hanning", windowoverlap=None, tbounds=None,
+                onesided=None, nwins=None, tper=None, minFreq=None, sigy=None, beta=None):
+    """fftanal.init geometry  (fft_analysis.py:1713-1783).  `nwins=` overrides (Q5 escape hatch)."""
+    if windowoverlap is None:
+        windowoverlap = windows(windowfunction, beta=beta)
+    if tbounds is None:
+        tbounds = [tvec.min(), tvec.max()]
+    if onesided is None:
+        onesided = not (np.iscomplexobj(sigx) or (sigy is not None and np.iscomplexobj(sigy)))
+    Fs = get_fs(tvec)
+    ib = get_ibounds(tvec, tbounds)
+    nsig = np.size(tvec[ib[0]:ib[1]])
+    calc = False
+    if Navr is None:
+        calc = True
+        Navr = 8
+    if minFreq is not None:
+        tper = 2.0 / minFreq
+    if nwins is not None:
+        calc = True
+    elif tper is not None:
+        nwins = int(Fs * tper)                                   # :1770 (Q5)
+    else:
+        calc = False
+        nwins = get_nwins(nsig, Navr, windowoverlap)
+    noverlap = get_noverlap(nwins, windowoverlap)
+    if calc:
+        Navr = get_navr(nsig, nwins, noverlap)
+    win = windows(windowfunction, nwins=nwins, beta=beta)
+    Nny = get_nnyquist(nwins)
+    S1, S2, NENBW, ENBW = get_norms(win, Nny, Fs)
+    return dict(Fs=Fs, ibounds=ib, nsig=nsig, nwins=nwins, noverlap=noverlap, Navr=Navr, win=win, Nnyquist=Nny,
+                S1=S1, S2=S2, NENBW=NENBW, ENBW=ENBW, onesided=onesided, overlap=windowoverlap)
+
+
+# --------------------------------------------------------------------------- #
+# A4  Xstft / Pstft / averagewins                    fft_analysis.py:1924-2018
+# --------------------------------------------------------------------------- #
+def pwelch_class(tvec, sigx, sigy=None, detrend_style=1, **kw):
+    """fftanal(...).pwelch() -> dict with the attributes the class sets."""
+    g = class_setup(tvec, sigx, sigy=sigy, **kw)
+    i0, i1 = g["ibounds"]
+    t = tvec[i0:i1]
+    out = dict(g)
+    args = (g["win"], g["nwins"], g["noverlap"], g["Navr"], g["onesided"], g["S1"], g["S2"], g["ENBW"], detrend_style)
+    out["tseg"], out["freq"], Xseg, out["Xpow"] = fft_win(sigx[i0:i1], t, *args)
+    out["Xseg"] = Xseg
+    out["Xfft"] = Xseg.mean(axis=0)                              # :1931
+    out["Pxx_seg"] = Xseg * np.conj(Xseg)                        # :1946
+    amp = np.sqrt(2) if g["onesided"] else 1.0
+    out["Lxx_seg"] = amp * np.sqrt(np.abs(g["ENBW"] * out["Pxx_seg"]))
+    out["Pxx"] = out["Pxx_seg"].mean(axis=0)                     # :1980
+    out["varPxx"] = (out["Pxx"] / np.sqrt(g["Navr"])) ** 2.0     # :1988
+    if sigy is not None and sigy is not sigx:
+        _, _, Yseg, out["Ypow"] = fft_win(sigy[i0:i1], t, *args)
+        out["Yseg"] = Yseg
+        out["Yfft"] = Yseg.mean(axis=0)
+        out["Pyy_seg"] = Yseg * np.conj(Yseg)                    # :1953
+        out["Pxy_seg"] = Xseg * np.conj(Yseg)                    # :1960  (Q4: X.conj(Y) on the class path)
+        out["phixy_seg"] = np.angle(out["Pxy_seg"])
+        out["Pyy"] = out["Pyy_seg"].mean(axis=0)
+        out["Pxy"] = out["Pxy_seg"].mean(axis=0)
+        out["phi_xy"] = np.angle(out["Pxy"])
+    return out
+
+
+def welch_psd_stream(x, win, nfft, hop, nframes, Fs, detrend_style=1, chunk=4096):
+    """Streaming two-sided (shifted) Welch PSD of the class path: identical arithmetic to
+    fft_win -> Pstft -> averagewins (fft_analysis.py:2126-2203, :1946, :1980) without the [M,N]
+    temporaries, so the 2^28-sample metric fits in RAM.  Used as bench.py's cpu_baseline ("port")."""
+    x = np.asarray(x)
+    if detrend_style and detrend_style > 0:
+        x = x - x.mean()                                         # input dtype (Q6)
+    S2 = np.sum(win ** 2.0)
+    acc = np.zeros(nfft, dtype=np.float64)
+    idx = np.arange(nfft)[None, :]
+    for g0 in range(0, nframes, chunk):
+        g1 = min(nframes, g0 + chunk)
+        starts = (np.arange(g0, g1) * hop)[:, None]
+        seg = win[None, :] * x[starts + idx]                     # float64 window => complex128 math
+        X = np.fft.fft(seg, axis=-1)
+        acc += (X.real ** 2 + X.imag ** 2).sum(axis=0)
+    return np.fft.fftshift(acc) / (nframes * Fs * S2)            # /S1^2/ENBW == /(Fs*S2)
+
+
+# --------------------------------------------------------------------------- #
+# A5/A6  fft_pwelch                                    fft_analysis.py:36-648
+# --------------------------------------------------------------------------- #
+def cxy_cxy2(Pxx, Pyy, Pxy):                                     # :1662-1680
+    Pxx = np.atleast_2d(Pxx.copy())
+    if np.size(Pxx, axis=1) != np.size(Pyy, axis=1):
+        Pxx = Pxx.T * np.ones((1, np.size(Pyy, axis=1)), dtype=Pxx.dtype)
+    Cxy2 = Pxy * np.conj(Pxy) / (np.abs(Pxx) * np.abs(Pyy))
+    Cxy = Pxy / np.sqrt(np.abs(Pxx) * np.abs(Pyy))
+    return Cxy, Cxy2
+
+
+def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, windowfunction=None,
+               detrend_style=None, onesided=None, tper=None, minFreq=None):
+    """Homebrew branch of fft_pwelch (useMLAB=False).  Returns (freq, Pxy, Pxx, Pyy, Cxy, phi_xy, info-dict)."""
+    calcNavr = Navr is None
+    if windowfunction is None:
+        windowfunction = "Hanning"
+    if windowoverlap is None:
+        windowoverlap = windows(windowfunction)
+    if detrend_style is None:
+        detrend_style = 1
+    if tbounds is None:
+        tbounds = [tvec[0], tvec[-1]]
+    if onesided is None:
+        onesided = not (np.iscomplexobj(sigx) or np.iscomplexobj(sigy))
+    Fs = (len(tvec) - 1) / (tvec[-1] - tvec[0])                   # :136
+    i0 = int(np.floor(Fs * (tbounds[0] - tvec[0])))               # :143
+    i1 = int(np.floor(1 + Fs * (tbounds[1] - tvec[0])))           # :144
+    nsig = np.size(tvec[i0:i1])
+    sigy = np.atleast_2d(sigy)
+    if sigy.shape[1] == len(tvec):
+        sigy = sigy.T
+    nch = sigy.shape[1]
+    if sigx.shape[0] != sigy.shape[0]:
+        raise NotImplementedError("nTmodel branch (fft_analysis.py:170-176) is outside the hot-path scope")
+    if minFreq is not None:
+        tper = 2.0 / minFreq                                      # :180-181
+    if tper is not None:
+        nwins = int(Fs * tper)                                    # :183 (Q5)
+    else:
+        if Navr is None:
+            Navr = 8
+        calcNavr = False
+        nwins = get_nwins(nsig, Navr, windowoverlap)              # :189
+    noverlap = get_noverlap(nwins, windowoverlap)                 # :194
+    reflecting = False
+    if i0 == 0 and i1 == len(tvec):                               # :197-205 (Q2)
+        reflecting = True
+        sigx = np.concatenate((sigx[nwins - 1:0:-1, ...], sigx, sigx[-1:-nwins:-1, ...]), axis=0)
+        sigy = np.concatenate((sigy[nwins - 1:0:-1, ...], sigy, sigy[-1:-nwins:-1, ...]), axis=0)
+        nsig = sigx.shape[0]
+    if calcNavr:
+        Navr = get_navr(nsig, nwins, noverlap)                    # :209
+    if nwins >= nsig:
+        Navr = 1
+        nwins = nsig
+    nfft = nwins
+    Nny = get_nnyquist(nfft)
+    win = windows(windowfunction, nwins=nwins)
+    S1, S2, NENBW, ENBW = get_norms(win, Nny, Fs)
+
+    x_in = detrend(sigx[i0:i1], detrend_style)                   # :353-357
+    y_in = detrend(sigy[i0:i1, :], detrend_style)
+    hop = nwins - noverlap
+    Xfft = np.zeros((Navr, nfft), dtype=np.complex128)
+    Yfft = np.zeros((nch, Navr, nfft), dtype=np.complex128)
+    for g in range(Navr):                                         # :362-388
+        a = g * hop
+        Xfft[g] = np.fft.fft(win * x_in[a:a + nwins], n=nfft, axis=0)
+        Yfft[:, g, :] = np.fft.fft(win[:, None] * y_in[a:a + nwins, :], n=nfft, axis=0).T
+    Pxx_seg = Xfft * np.conj(Xfft)                                # :391-393
+    Pyy_seg = Yfft * np.conj(Yfft)
+    Pxy_seg = Yfft * np.conj(Xfft)[None, :, :]                    # Q4: Y.conj(X) on the function path
+    freq = np.fft.fftfreq(nfft, 1.0 / Fs)
+    if onesided:                                                  # :402-421
+        freq = freq[:Nny]
+        Pxx_seg = Pxx_seg[:, :Nny].copy()
+        Pyy_seg = Pyy_seg[:, :, :Nny].copy()
+        Pxy_seg = Pxy_seg[:, :, :Nny].copy()
+        Pxx_seg[:, 1:-1] *= 2
+        Pyy_seg[:, :, 1:-1] *= 2
+        Pxy_seg[:, :, 1:-1] *= 2
+        if nfft % 2:
+            Pxx_seg[:, -1] *= 2
+            Pyy_seg[:, :, -1] *= 2
+            Pxy_seg[:, :, -1] *= 2
+    else:                                                         # :423-427
+        freq = np.fft.fftshift(freq)
+        Pxx_seg = np.fft.fftshift(Pxx_seg, axes=-1)
+        Pyy_seg = np.fft.fftshift(Pyy_seg, axes=-1)
+        Pxy_seg = np.fft.fftshift(Pxy_seg, axes=-1)
+    Pxx_seg = (1.0 / S1 ** 2) * Pxx_seg / ENBW                    # :432-440
+    Pyy_seg = (1.0 / S1 ** 2) * Pyy_seg / ENBW
+    Pxy_seg = (1.0 / S1 ** 2) * Pxy_seg / ENBW
+    Pxx = Pxx_seg.mean(axis=0)                                    # :444-446
+    Pyy = Pyy_seg.mean(axis=1).T
+    Pxy = Pxy_seg.mean(axis=1).T
+    info = dict(S1=S1, S2=S2, NENBW=NENBW, ENBW=ENBW, nwins=nwins, noverlap=noverlap, Navr=Navr, Fs=Fs, nch=nch,
+                ibnds=[i0, i1], win=win, reflecting=reflecting, Xfft_seg=Xfft, Yfft_seg=Yfft, Pxy_seg=Pxy_seg,
+                Pxx_seg=Pxx_seg, Pyy_seg=Pyy_seg, minFreq=2.0 * Fs / nwins)
+    out = pwelch_epilogue(freq, Pxx, Pyy, Pxy, info, onesided)
+    return out
+
+
+def pwelch_epilogue(freq, Pxx, Pyy, Pxy, info, onesided):
+    """fft_analysis.py:489-648 -- coherence, phase, amplitudes, correlations (host-side, length-N work)."""
+    Navr, ENBW, nfft, Fs, nch = info["Navr"], info["ENBW"], info["nwins"], info["Fs"], info["nch"]
+    Nny = get_nnyquist(nfft)
+    Cxy, Cxy2 = cxy_cxy2(Pxx, Pyy, Pxy)                           # :489
+    info["varCxy"] = ((1.0 - Cxy * np.conjugate(Cxy)) / np.sqrt(2 * Navr)) ** 2.0
+    info["varCxy2"] = 4.0 * Cxy2 * info["varCxy"]
+    info["varPxx"] = (Pxx / np.sqrt(Navr)) ** 2.0
+    info["varPyy"] = (Pyy / np.sqrt(Navr)) ** 2.0
+    info["varPxy"] = (Pxy / np.sqrt(Navr)) ** 2.0
+    info["varPhxy"] = (np.sqrt(1.0 - np.abs(Cxy2))) / np.sqrt(2 * Navr * np.sqrt(np.abs(Cxy2))) ** 2.0
+    phi_xy = np.arctan2(Pxy.imag, Pxy.real)                       # :520
+    Lxx = np.sqrt(np.abs(ENBW * Pxx))
+    Lyy = np.sqrt(np.abs(ENBW * Pyy))
+    Lxy = np.sqrt(np.abs(ENBW * Pxy))
+    if onesided:                                                  # :530-563
+        Lxx[1:-1] *= np.sqrt(2)
+        Lyy[1:-1, :] *= np.sqrt(2)
+        Lxy[1:-1, :] *= np.sqrt(2)
+        if nfft % 2:
+            Lxx[-1] *= np.sqrt(2)
+            Lyy[-1, :] *= np.sqrt(2)
+            Lxy[-1, :] *= np.sqrt(2)
+
+        def back(P):
+            R = P.copy()
+            R[1:-1, ...] *= 0.5
+            if nfft % 2:
+                R[-1, ...] *= 0.5
+            return np.fft.irfft(R, n=nfft, axis=0)
+        Rxx, Ryy, Rxy = back(Pxx), back(Pyy), back(Pxy)
+        iCxy = np.fft.irfft(Cxy.copy(), n=nfft, axis=0)
+    else:                                                         # :571-574
+        Rxx = np.fft.ifft(np.fft.ifftshift(Pxx, axes=0), n=nfft, axis=0)
+        Ryy = np.fft.ifft(np.fft.ifftshift(Pyy, axes=0), n=nfft, axis=0)
+        Rxy = np.fft.ifft(np.fft.ifftshift(Pxy, axes=0), n=nfft, axis=0)
+        iCxy = np.fft.ifft(np.fft.ifftshift(Cxy, axes=0), n=nfft, axis=0)
+    s = np.sqrt(nfft)
+    Rxx, Ryy, Rxy, iCxy = Rxx * s, Ryy * s, Rxy * s, iCxy * s     # :579-582
+    Ex = Rxx[0, ...].copy()
+    Ey = Ryy[0, ...].copy()
+    corrcoef = Rxy / np.sqrt(np.ones((nfft, 1), dtype=Rxy.dtype) * (Ex * Ey))     # :590
+    Rxx, Ryy, Rxy, iCxy, corrcoef = [np.fft.fftshift(a, axes=0) for a in (Rxx, Ryy, Rxy, iCxy, corrcoef)]
+    lags = (np.asarray(range(1, nfft + 1), dtype=int) - Nny) / Fs  # :597
+    info.update(Lxx=Lxx, Lyy=Lyy, Lxy=Lxy, Rxx=Rxx, Ryy=Ryy, Rxy=Rxy, iCxy=iCxy, Ex=Ex, Ey=Ey,
+                corrcoef=corrcoef, lags=lags, Cxy2=Cxy2)
+    info["varLxx"] = (Lxx ** 2) * (info["varPxx"] / np.abs(Pxx) ** 2)
+    info["varLyy"] = (Lyy ** 2) * (info["varPyy"] / np.abs(Pyy) ** 2)
+    info["varLxy"] = (Lxy ** 2) * (info["varPxy"] / np.abs(Pxy) ** 2)
+    if nch == 1:                                                  # :605-631
+        Pyy, Pxy, Cxy, phi_xy = Pyy.flatten(), Pxy.flatten(), Cxy.flatten(), phi_xy.flatten()
+        for k in ("Cxy2", "lags", "Rxx", "Ryy", "Rxy", "corrcoef", "iCxy", "Lxx", "Lyy", "Lxy", "varLxx", "varLyy",
+                  "varLxy", "varCxy", "varCxy2", "varPxx", "varPyy", "varPxy", "varPhxy"):
+            info[k] = info[k].flatten()
+    return freq, Pxy, Pxx, Pyy, Cxy, phi_xy, info
+
+
+# --------------------------------------------------------------------------- #
+# A8/A9  spectrogram.stft / specgram                     spectrogram.py:49-168
+# --------------------------------------------------------------------------- #
+def stft(tt, y, tper=None, returnclass=True, **kw):
+    """spectrogram.py:140-168 -> fftanal.init(tper=...) + .stft() == pwelch() on the class path."""
+    if tper is None:
+        tper = (tt[-1] - tt[0]) / 20
+    out = pwelch_class(tt, y, tper=tper, **kw)
+    if returnclass:
+        return out
+    twin = np.linspace(tt[0], tt[-1], num=out["Navr"], endpoint=True)
+    return twin, out["freq"], out["Xseg"]
+
+
+def specgram(t, s, wl=512, hanning=True, overlap=True):
+    """spectrogram.py:49-134 (windowAverage=None branch; the averaging branch is un-runnable on py3:
+    float slice sizes at :116-118)."""
+    s = s.flatten()
+    n = len(s)
+    dt = np.abs(t[1] - t[0])
+    nWindows = (2 * (n - (n % wl)) // wl - 1) if overlap else ((n - (n % wl)) // wl - 1)
+    out = np.zeros((wl, nWindows))
+    w = np.hanning(wl)                                            # symmetric Hann (:109)
+    for i in range(nWindows):
+        a = i * wl // 2 if overlap else i * wl
+        if hanning:
+            out[:, i] = np.sqrt(8.0 / 3.0) * np.abs(np.fft.fft(w * s[a:a + wl])) ** 2 / wl
+        else:
+            out[:, i] = np.abs(np.fft.fft(s[a:a + wl])) ** 2 / wl
+    fAxis = np.fft.fftfreq(wl, dt)
+    if overlap:
+        time = np.linspace(t[0] + wl * dt / 2, t[0] + wl * dt * ((nWindows / 2 - 1) + 1 / 2), num=nWindows)
+    else:
+        time = np.linspace(t[0] + wl * dt / 2, t[0] + wl * dt * ((nWindows - 1) + 1 / 2), num=nWindows)
+    return time, fAxis, out
+
+
+# --------------------------------------------------------------------------- #
+# A10  hilbert                                                hilbert.py:22-112
+# --------------------------------------------------------------------------- #
+def hilbert(uin, nfft=None, axes=-1):
+    if nfft is None:
+        uin = np.atleast_1d(uin)
+        nfft = np.shape(uin)[axes]
+    nyq = (nfft + 1) // 2 if nfft % 2 else nfft // 2              # :47-50 (odd-N quirk, Q6)
+    U = np.fft.fft(uin, n=nfft, axis=axes)                        # input-dtype precision under numpy>=2
+    U[(slice(None),) * (axes % U.ndim) + (slice(nyq + 1, None),)] = 0.0
+    U[(slice(None),) * (axes % U.ndim) + (slice(1, nyq),)] *= 2.0
+    return np.fft.ifft(U, n=nfft, axis=axes).squeeze()
+
+
+def hilbert_1d(uin, nfft=None):                                  # :70-112
+    if nfft is None:
+        uin = np.atleast_1d(uin)
+        nfft = len(uin)
+    nyq = (nfft + 1) // 2 if nfft % 2 else nfft // 2
+    U = np.fft.fft(uin, n=nfft, axis=-1)
+    h = np.zeros(nfft)
+    h[0] = 1.0
+    h[1:nyq] = 2.0
+    h[nyq] = 1.0
+    return np.fft.ifft(U * h, n=nfft, axis=-1)
+
+
+# --------------------------------------------------------------------------- #
+# A11  ccf                                                        ccf.py:66-77
+# --------------------------------------------------------------------------- #
+def ccf(x1, x2, fs):
+    npts = len(x1)
+    lags = np.arange(-npts + 1, npts)
+    tau = -lags / float(fs)
+    ccov = np.correlate(x1 - x1.mean(), x2 - x2.mean(), mode="full")
+    return tau, ccov / (npts * x1.std() * x2.std())
+
+
+def ccf_fft(x1, x2, fs):
+    """Same result as ccf() through zero-padded FFTs (what the GPU kernel does); O(N log N) so the oracle
+    also finishes at sizes where np.correlate cannot.  Equality with ccf() is asserted in the CPU tests."""
+    n = len(x1)
+    L = 1 << int(np.ceil(np.log2(2 * n)))
+    a = np.fft.rfft(x1 - x1.mean(), L)
+    b = np.fft.rfft(x2 - x2.mean(), L)
+    r = np.fft.irfft(a * np.conj(b), L)
+    ccov = np.concatenate([r[L - n + 1:], r[:n]])
+    return -np.arange(-n + 1, n) / float(fs), ccov / (n * x1.std() * x2.std())
+
+
+# --------------------------------------------------------------------------- #
+# A12  notch / peak biquad design                      notch_filter.py:175-241
+# --------------------------------------------------------------------------- #
+def _design_notch_peak(w0, Q, ftype):
+    w0 = float(w0)
+    Q = float(Q)
+    if w0 > 1.0 or w0 < 0.0:
+        raise ValueError("w0 should be such that 0 < w0 < 1")
+    bw = (w0 / Q) * np.pi
+    w0 = w0 * np.pi
+    gb = 1 / np.sqrt(2)
+    if ftype == "notch":
+        beta = (np.sqrt(1.0 - gb ** 2.0) / gb) * np.tan(bw / 2.0)
+    else:
+        beta = (gb / np.sqrt(1.0 - gb ** 2.0)) * np.tan(bw / 2.0)
+    gain = 1.0 / (1.0 + beta)
+    if ftype == "notch":
+        b = gain * np.array([1.0, -2.0 * np.cos(w0), 1.0])
+    else:
+        b = (1.0 - gain) * np.array([1.0, 0.0, -1.0])
+    a = np.array([1.0, -2.0 * gain * np.cos(w0), (2.0 * gain - 1.0)])
+    return b, a
+
+
+def iirnotch(w0, Q):
+    return _design_notch_peak(w0, Q, "notch")
+
+
+def iirpeak(w0, Q):
+    return _design_notch_peak(w0, Q, "peak")
+
+
+# --------------------------------------------------------------------------- #
+# F1/F2  build-defined (absent from the reference): causal FIR by overlap-add, notch application
+#        Nearest reference code: filters.py:282 (np.convolve FIR), ccf.py:283 (fftconvolve).
+#        PARITY UNPINNED against the reference (nothing to pin to); pinned against scipy.signal.lfilter.
+# --------------------------------------------------------------------------- #
+def fftfilt(b, x):
+    """y = lfilter(b, 1, x): causal FIR, output truncated to len(x)."""
+    x = np.asarray(x)
+    return np.convolve(x, np.asarray(b, dtype=np.float64))[:x.shape[0]]
+
+
+def biquad_fir(b, a, ntaps):
+    """First ntaps samples of the impulse response of b/a (second order), by the recursion itself."""
+    h = np.zeros(ntaps)
+    for n in range(ntaps):
+        acc = b[n] if n < len(b) else 0.0
+        for k in range(1, len(a)):
+            if n - k >= 0:
+                acc -= a[k] * h[n - k]
+        h[n] = acc / a[0]
+    return h
+
+
+def notch_apply(x, w0, Q, ntaps=513, ftype="notch"):
+    """Truncated-impulse-response FIR realisation of the designed biquad (SURVEY.md F2 option (i))."""
+    b, a = _design_notch_peak(w0, Q, ftype)
+    return fftfilt(biquad_fir(b, a, ntaps), x)
+
+
+# --------------------------------------------------------------------------- #
+# A7  plain transforms (convention: forward unnormalised e^{-j}, inverse 1/N)     dft.py:108-133,242-290
+# --------------------------------------------------------------------------- #
+def fft(x, n=None, axis=-1):
+    return np.fft.fft(x, n=n, axis=axis)
+
+
+def ifft(x, n=None, axis=-1):
+    return np.fft.ifft(x, n=n, axis=axis)
+
+
+# --------------------------------------------------------------------------- #
+# multi-channel CSD (cfg5): build-defined generalisation of fft_pwelch's ref x channels loop
+#   (fft_analysis.py:387-393, HeatPulse_Funcs.py:576-583).  G[k,i,j] = mean_g X_i[g,k] conj(X_j[g,k]) / (Fs*S2)
+# --------------------------------------------------------------------------- #
+def csd_matrix(x, win, nfft, hop, nframes, Fs, detrend_style=1):
+    """x: [nch, nsig] real.  Returns one-sided-uncropped G[nfft//2+1, nch, nch] complex128 (no doubling)."""
+    x = np.asarray(x, dtype=np.float64)
+    if detrend_style and detrend_style > 0:
+        x = x - x.mean(axis=1, keepdims=True)
+    nch = x.shape[0]
+    nb = nfft // 2 + 1
+    S2 = np.sum(win ** 2.0)
+    G = np.zeros((nb, nch, nch), dtype=np.complex128)
+    for g in range(nframes):
+        X = np.fft.rfft(win[None, :] * x[:, g * hop:g * hop + nfft], axis=-1)     # [nch, nb]
+        G += X.T[:, :, None] * np.conj(X.T[:, None, :])
+    return G / (nframes * Fs * S2)

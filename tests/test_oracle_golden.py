@@ -1,0 +1,239 @@
+"""Pin the CPU oracle (oracle/cpu_ref.py) to the reference: every fixture in tests/golden/ was produced by
+running the reference's own modules (tests/golden/make_golden.py); plus the reference's known-answer material.
+CPU-only.  float64 everywhere -> rtol 1e-12 unless stated."""
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as O
+from conftest import load_golden
+
+RT = 1e-12
+
+
+def close(a, b, rtol=RT, atol=0.0):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = np.max(np.abs(b)) if b.size else 1.0
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol + 1e-13 * scale)
+
+
+# ------------------------------------------------------------------ windows (A1)
+WNAMES = ["Hanning", "Hamming", "Blackman", "SFT3F", "SFT4F", "SFT5F", "SFT3M", "SFT4M", "SFT5M", "Nuttall3a",
+          "Nuttall3b", "Nuttall3", "Nuttall4a", "Nuttall4b", "Nuttall4c", "Nuttall4", "Kaiser", "Welch", "Bartlett",
+          "box"]
+
+
+@pytest.mark.parametrize("name", WNAMES)
+def test_windows_catalogue(name):
+    g = load_golden("windows")
+    kw = {"beta": 8.6} if name == "Kaiser" else {}
+    for N in (16, 255, 1024):
+        close(O.windows(name, nwins=N, **kw), g["%s_per_%d" % (name, N)])
+        close(O.windows(name, nwins=N, periodic=False, **kw), g["%s_sym_%d" % (name, N)])
+    assert O.windows(name, **kw) == float(g["%s_rov" % name])
+
+
+def test_window_constants_heinzel():
+    # windows.py:68-70 / Heinzel: Hann ROV 50 %, NENBW 1.5 bins (true N), S1 = N/2, S2 = 3N/8 for the periodic form
+    w = O.windows("Hanning", nwins=4096)
+    assert O.windows("Hanning") == 0.5
+    assert abs(w.sum() - 2048.0) < 1e-9 and abs((w ** 2).sum() - 1536.0) < 1e-9
+    assert abs(4096 * (w ** 2).sum() / w.sum() ** 2 - 1.5) < 1e-12
+
+
+# ------------------------------------------------------------------ geometry (A2)
+def test_geometry_table():
+    g = load_golden("geometry")
+    for nsig, Navr, ov, nw, no, na, nyq in g["table"]:
+        nwins = O.get_nwins(int(nsig), int(Navr), ov)
+        assert nwins == int(nw)
+        assert O.get_noverlap(nwins, ov) == int(no)
+        assert O.get_navr(int(nsig), nwins, int(no)) == int(na)
+        assert O.get_nnyquist(nwins) == int(nyq)
+    close(np.array(O.get_norms(O.windows("Hanning", nwins=4096), 2048, 1.0)), g["hann4096_norms"])
+
+
+# ------------------------------------------------------------------ class path (A3, A4)
+@pytest.mark.parametrize("tag", ["c64_2e16_n4096", "c64_2e14_n1024"])
+def test_class_welch_complex(tag):
+    g = load_golden("welch_class_" + tag)
+    x = g["x"]
+    t = np.arange(x.size, dtype=np.float64)
+    r = O.pwelch_class(t, x, nwins=int(g["nwins"]), windowfunction="Hanning", windowoverlap=0.5,
+                       tbounds=[t[0], t[-1]])
+    assert r["Navr"] == int(g["Navr"]) and r["noverlap"] == int(g["noverlap"]) and not r["onesided"]
+    for k in ("S1", "S2", "ENBW", "NENBW", "Fs"):
+        close(r[k], g[k])
+    close(r["freq"], g["freq"])
+    close(r["tseg"], g["tseg"])
+    close(r["Pxx"], g["Pxx"], rtol=1e-11)
+    close(r["varPxx"], g["varPxx"], rtol=1e-11)
+    close(r["Xfft"], g["Xfft"], rtol=1e-9, atol=1e-12)
+    close(r["Xpow"], g["Xpow"], rtol=1e-11)
+    close(r["Xseg"][:4], g["Xseg_head"], rtol=1e-10, atol=1e-12)
+    close(r["Xseg"][-2:], g["Xseg_tail"], rtol=1e-10, atol=1e-12)
+    close(r["Pxx_seg"][:2], g["Pxx_seg_head"], rtol=1e-10)
+    # the streaming restatement used for the CPU baseline is the same arithmetic
+    ps = O.welch_psd_stream(x, r["win"], r["nwins"], r["nwins"] - r["noverlap"], r["Navr"], r["Fs"], chunk=7)
+    close(ps, g["Pxx"].real, rtol=1e-11)
+
+
+@pytest.mark.parametrize("wname", ["Hamming", "SFT3F"])
+def test_class_welch_real_onesided(wname):
+    g = load_golden("welch_class_real_" + wname)
+    t, x, y = g["t"], g["x"], g["y"]
+    r = O.pwelch_class(t, x, y, Navr=31, windowfunction=wname, tbounds=[t[0], t[-1]])
+    assert r["onesided"] and r["nwins"] == int(g["nwins"]) and r["noverlap"] == int(g["noverlap"])
+    assert r["Navr"] == int(g["Navr"])
+    close(r["freq"], g["freq"])
+    for k in ("Pxx", "Pyy", "Pxy"):
+        close(r[k], g[k], rtol=1e-10, atol=1e-18)
+    close(r["Xseg"][:3], g["Xseg_head"], rtol=1e-10, atol=1e-12)
+    close(r["Yseg"][:3], g["Yseg_head"], rtol=1e-10, atol=1e-12)
+    close(r["Lxx_seg"][:2], g["Lxx_seg_head"], rtol=1e-10, atol=1e-12)
+    close(r["Xpow"], g["Xpow"], rtol=1e-11)
+
+
+# ------------------------------------------------------------------ function path (A5, A6)
+PW = {
+    "pwelch_cfg1": dict(Navr=127, windowoverlap=0.5, windowfunction="Hanning", tb=-2),
+    "pwelch_reflect": dict(Navr=15, windowfunction="Hanning", tb=None),
+    "pwelch_2ch_twosided": dict(Navr=31, windowfunction="Hamming", onesided=False, detrend_style=0, tb=-2),
+    "pwelch_minfreq_linear": dict(minFreq=2.0 * 1.0e4 / 1024.0 * 1.0000001, detrend_style=-1, tb=-2),
+    "pwelch_selftest_navr8": dict(Navr=8, windowfunction="hamming", detrend_style=1, tb=-1),
+    "pwelch_selftest_minfreq": dict(minFreq=75.0, detrend_style=1, tb=-1),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(PW))
+def test_fft_pwelch(tag):
+    g = load_golden(tag)
+    kw = dict(PW[tag])
+    tb = kw.pop("tb")
+    t, x, y = g["t"], g["x"], g["y"]
+    tbounds = None if tb is None else [t[0], t[tb]]
+    freq, Pxy, Pxx, Pyy, Cxy, phi, info = O.fft_pwelch(t, x, y, tbounds=tbounds, **kw)
+    for k in ("nwins", "noverlap", "Navr", "nch"):
+        assert int(info[k]) == int(g["info_" + k]), k
+    assert list(info["ibnds"]) == list(g["info_ibnds"])
+    for k in ("S1", "S2", "ENBW", "NENBW", "Fs", "minFreq"):
+        close(info[k], g["info_" + k])
+    close(freq, g["freq"])
+    # linear detrend goes through a different LS solver than scipy's -> slightly looser
+    rt = 1e-7 if kw.get("detrend_style", 1) < 0 else 1e-9
+    at = 1e-9 * float(np.max(np.abs(g["Pxx"])))
+    close(Pxx, g["Pxx"], rtol=rt, atol=at)
+    close(Pyy, g["Pyy"], rtol=rt, atol=at)
+    close(Pxy, g["Pxy"], rtol=rt, atol=at)
+    close(info["Xfft_seg"][:2], g["Xfft_seg_head"], rtol=rt, atol=1e-9 * np.abs(g["Xfft_seg_head"]).max())
+    if tag in ("pwelch_cfg1", "pwelch_2ch_twosided", "pwelch_reflect"):
+        # epilogue quantities: only where no bin is ~0/0 (the self-test inputs are noise-free -> coherence of
+        # rounding noise is ill-conditioned; those are compared through Pxx/Pyy/Pxy above)
+        close(Cxy, g["Cxy"], rtol=1e-7, atol=1e-9)
+        close(phi, g["phi_xy"], rtol=1e-6, atol=1e-7)
+        for k in ("Lxx", "Lyy", "Lxy", "Rxx", "Ryy", "Rxy", "corrcoef", "lags", "Ex", "Ey", "varPxx", "varPyy"):
+            gk = g["info_" + k]
+            # (np.ascontiguousarray in the generator promoted 0-d values to 1-d)
+            close(np.atleast_1d(info[k]), gk, rtol=1e-7, atol=1e-9 * float(np.max(np.abs(gk))))
+
+
+# ------------------------------------------------------------------ stft / specgram (A8, A9)
+def test_stft_class_f32():
+    g = load_golden("stft_f32_n2048_ov75")
+    r = O.stft(g["t"], g["x"], tper=2048.5, windowfunction="Hanning", windowoverlap=0.75)
+    assert r["nwins"] == 2048 and r["noverlap"] == 1536 and r["Navr"] == int(g["Navr"]) and r["onesided"]
+    close(r["freq"], g["freq"])
+    close(r["tseg"], g["tseg"])
+    M = r["Navr"]
+    at = 1e-9 * float(np.abs(g["Xseg_head"]).max())
+    close(r["Xseg"][:3], g["Xseg_head"], rtol=1e-9, atol=at)
+    close(r["Xseg"][M // 2:M // 2 + 2], g["Xseg_mid"], rtol=1e-9, atol=at)
+    close(r["Xseg"][-2:], g["Xseg_tail"], rtol=1e-9, atol=at)
+    close(r["Pxx"], g["Pxx"], rtol=1e-9, atol=1e-9 * float(np.abs(g["Pxx"]).max()))
+    close(r["Xpow"], g["Xpow"], rtol=1e-9)
+
+
+def test_stft_tuple():
+    g = load_golden("stft_tuple_n256")
+    twin, freq, Xseg = O.stft(g["t"], g["x"], tper=256.5, returnclass=False, windowfunction="Hamming")
+    close(twin, g["twin"])
+    close(freq, g["freq"])
+    close(Xseg, g["Xseg"], rtol=1e-10, atol=1e-12)
+
+
+def test_specgram():
+    g = load_golden("specgram")
+    time1, f1, sp1 = O.specgram(g["t"], g["s"], wl=512, hanning=True, overlap=True)
+    close(time1, g["time1"]); close(f1, g["f1"]); close(sp1, g["sp1"], rtol=1e-11, atol=1e-13)
+    time2, f2, sp2 = O.specgram(g["t"], g["s"], wl=500, hanning=False, overlap=False)
+    close(time2, g["time2"]); close(f2, g["f2"]); close(sp2, g["sp2"], rtol=1e-11, atol=1e-13)
+
+
+# ------------------------------------------------------------------ hilbert (A10)
+def test_hilbert_golden():
+    g = load_golden("hilbert")
+    close(O.hilbert(g["yk"]), g["zk"], atol=1e-15)
+    close(O.hilbert_1d(g["yk"]), g["zk1d"], atol=1e-15)
+    close(O.hilbert(g["u_even"]), g["z_even"], atol=1e-14)
+    close(O.hilbert(g["u_odd"]), g["z_odd"], atol=1e-14)
+    close(O.hilbert_1d(g["u_odd"]), g["z_odd_1d"], atol=1e-14)
+    close(O.hilbert(g["u_2d"]), g["z_2d"], atol=1e-14)
+    close(O.hilbert(g["u_2d"], axes=0), g["z_2d_ax0"], atol=1e-14)
+    z32 = O.hilbert(g["u_f32"])
+    assert z32.dtype == g["z_f32"].dtype
+    close(z32, g["z_f32"], rtol=1e-6, atol=1e-6)
+    close(O.hilbert(g["u_even"][:1000], nfft=1024), g["z_nfft"], atol=1e-14)
+
+
+def test_hilbert_known_answer():
+    # hilbert.py:115-140: one-cycle sine, analytic signal = y - j cos
+    N = 32
+    ph = 2 * np.pi * np.arange(N) / N
+    z = O.hilbert(np.sin(ph))
+    assert np.max(np.abs(z - (np.sin(ph) - 1j * np.cos(ph)))) < 1e-14
+
+
+# ------------------------------------------------------------------ ccf (A11)
+def test_ccf_golden_and_fft_form():
+    g = load_golden("ccf")
+    tau, co = O.ccf(g["x1"], g["x2"], float(g["fs"]))
+    close(tau, g["tau"]); close(co, g["co"], rtol=1e-11, atol=1e-14)
+    tau2, co2 = O.ccf(g["x3"], g["x4"], 1.0)
+    close(tau2, g["tau2"]); close(co2, g["co2"], rtol=1e-11, atol=1e-14)
+    # the FFT formulation the GPU kernel uses is the same function
+    tf, cf = O.ccf_fft(g["x1"], g["x2"], float(g["fs"]))
+    close(tf, g["tau"]); close(cf, g["co"], rtol=1e-9, atol=1e-13)
+    # ccf.py:139-148: expected lag of the maximum = -phi/(2 pi f) = -138.9 us (noisy input: within one period/8)
+    assert abs(tau[np.argmax(co)] - (-138.9e-6)) < 125e-6
+
+
+# ------------------------------------------------------------------ notch design (A12)
+def test_notch_design():
+    g = load_golden("notch")
+    b, a = O.iirnotch(60.0 / 100.0, 30.0)
+    close(b, g["b_doc"]); close(a, g["a_doc"])
+    for row in g["sweep"]:
+        w0, Q = row[0], row[1]
+        bn, an = O.iirnotch(w0, Q)
+        bp, ap = O.iirpeak(w0, Q)
+        close(np.concatenate([bn, an, bp, ap]), row[2:])
+    import scipy.signal as ss
+    bs, as_ = ss.iirnotch(0.6, 30.0)
+    close(b, bs); close(a, as_)
+    with pytest.raises(ValueError):
+        O.iirnotch(1.5, 3.0)
+
+
+# ------------------------------------------------------------------ build-defined FIR (F1/F2) vs scipy
+def test_fftfilt_and_notch_apply_vs_scipy():
+    import scipy.signal as ss
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(5000)
+    h = ss.firwin(513, 0.2)
+    close(O.fftfilt(h, x), ss.lfilter(h, 1.0, x), rtol=1e-10, atol=1e-12)
+    b, a = O.iirnotch(0.12, 5.0)
+    close(O.biquad_fir(b, a, 64), ss.lfilter(b, a, np.r_[1.0, np.zeros(63)]), rtol=1e-11, atol=1e-14)
+    # truncation error bound of the 513-tap realisation against the exact recursion
+    err = np.max(np.abs(O.notch_apply(x, 0.12, 5.0) - ss.lfilter(b, a, x)))
+    assert err < 1e-6 * np.max(np.abs(x))
