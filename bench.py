@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Msamples/s of Welch PSD, 4096-pt periodic Hann, 50 % overlap, complex64 stream
+(BASELINE.json metric; reference path fftanal.fft_win -> Pstft -> averagewins, fft_analysis.py:2126-2203,
+:1944-1990), on N GPUs of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic input: every rank runs the fused Welch PSD
+(mean-detrend pre-pass + windowed overlapped FFT + |X|^2 + segment average) over its own 2^28-sample segment of
+the stream, device-resident, then the ranks' 4096-bin accumulators are summed with one RCCL all-reduce (the only
+exchange the path has).  Weak scaling: per-GPU work is fixed, value = all samples / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  Extra objects: roofline (dominant kernel k_welch, HIP events on the launch
+stream), cpu_baseline (the CPU oracle `welch_psd_stream`, 1 core, bounded sample; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pyfft_amd import engine as E          # noqa: E402
+from pyfft_amd.windows import windows      # noqa: E402
+
+HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def synth_stream(n0, n, device, seed):
+    """complex64 samples [n0, n0+n) of the synthetic stream: unit-variance complex white
+    noise + the two Heinzel section-13 tones at fs = 1.  Noise comes from torch's device generator seeded per
+    segment; phases are evaluated in float64."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    out = torch.empty(n, dtype=torch.complex64, device=device)
+    chunk = 1 << 24
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        k = torch.arange(n0 + a, n0 + b, dtype=torch.float64, device=device)
+        noise = torch.randn((b - a, 2), generator=gen, dtype=torch.float32, device=device) * (0.5 ** 0.5)
+        z = torch.view_as_complex(noise).to(torch.complex128)
+        z = z + 2.82842712 * torch.exp(2j * np.pi * torch.remainder(0.1234 * k, 1.0))
+        z = z + 1.0 * torch.exp(2j * np.pi * torch.remainder(0.25002157 * k, 1.0))
+        z = z + (0.05 - 0.02j)                       # a small offset so the detrend has something to remove
+        out[a:b] = z.to(torch.complex64)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=28, help="samples per GPU = 2^log2n")
+    ap.add_argument("--nfft", type=int, default=4096)
+    ap.add_argument("--cpu-log2n", type=int, default=26, help="CPU-baseline sample = first 2^k samples (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    dist = None
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    nfft = args.nfft
+    hop = nfft // 2
+    S = 1 << args.log2n                                  # samples owned by this rank
+    total = S * world                                    # whole stream
+    M_total = (total - nfft) // hop + 1
+    # frames whose first sample lies in this rank's segment; the last rank has no halo to read
+    f0 = rank * (S // hop)
+    f1 = M_total if rank == world - 1 else (rank + 1) * (S // hop)
+    M_local = f1 - f0
+    n_local = (M_local - 1) * hop + nfft                 # includes the (nfft-hop)-sample halo on inner ranks
+    x = synth_stream(rank * S, n_local, dev, seed=0x5EED2024 + rank)
+
+    win = windows("Hanning", nwins=nfft, verbose=False)
+    S2 = float(np.sum(win ** 2))
+    Fs = 1.0
+    scale = 1.0 / (Fs * S2)
+
+    def step():
+        # global detrend (fft_analysis.py:2148): the stream mean.  At N>1 each rank removes its segment mean
+        # (the per-rank means are combined only in the accumulator; see DESIGN.md "multi-GPU")
+        p = E.welch_psd(x, win, hop, M_local, detrend=True, sided=E.SIDED_TWO, scale=scale)
+        if world > 1:
+            p = p * float(M_local)
+            dist.all_reduce(p)
+            p = p / float(M_total)
+        return p
+
+    E.profile_enable(True)
+    for _ in range(args.warmup):
+        pxx = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    kern_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pxx = step()
+        kern_ms.append(None)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # dominant-kernel duration, HIP events on the launch stream, measured in separate (untimed-region) steps so
+    # the event waits do not perturb the timed loop
+    kd = []
+    for _ in range(max(5, min(args.steps, 20))):
+        step()
+        kd.append(E.profile_last_ms())
+    torch.cuda.synchronize()
+    k_ms = float(np.mean(kd))
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = (total / 1e6) / (elapsed / args.steps)       # Msamples/s, whole job
+    alg_bytes = 8.0 * n_local                            # 8 B per complex64 input sample, read once
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9           # GB/s
+
+    result = {
+        "metric": "Msamples/sec Welch-PSD 4096-pt Hann 50% overlap, complex64",
+        "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Welch PSD, 2^%d complex64 samples per GPU, nfft=%d periodic Hann, hop=%d, "
+                               "global mean detrend, two-sided" % (args.log2n, nfft, hop),
+                   "samples_per_gpu": S, "frames_per_gpu": M_local, "parallelism": "segment-sharded x%d, "
+                   "one RCCL all-reduce of the %d-bin accumulator" % (world, nfft)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_welch<%d,complex64>" % nfft,
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+    }
+
+    if rank == 0 and world == 1 and args.cpu_log2n > 0:
+        # CPU baseline: the oracle's streaming restatement of the same path ("port"), 1 core, on the first
+        # 2^k samples of the same stream; doubles as the in-run parity gate.
+        from oracle import cpu_ref as O
+        nc = min(S, 1 << args.cpu_log2n)
+        Mc = (nc - nfft) // hop + 1
+        xc = x[:nc].cpu().numpy()
+        t1 = time.perf_counter()
+        ref = O.welch_psd_stream(xc, win, nfft, hop, Mc, Fs)
+        tc = time.perf_counter() - t1
+        got = E.welch_psd(x[:nc], win, hop, Mc, detrend=True, sided=E.SIDED_TWO, scale=scale).cpu().numpy()
+        err = float(np.max(np.abs(got - ref) / (2e-4 * np.abs(ref) + 1e-6 * ref.max())))
+        result["cpu_baseline"] = {"value": (nc / 1e6) / tc, "unit": "Msamples/s", "cores": 1, "kind": "port",
+                                  "sample": "first 2^%d samples of the same stream (%d frames), numpy float64 "
+                                            "pocketfft, %.1f s" % (args.cpu_log2n, Mc, tc),
+                                  "host_cores_available": os.cpu_count()}
+        result["parity"] = {"vs": "oracle.welch_psd_stream on the CPU sample", "rtol": 2e-4, "atol_rel_max": 1e-6,
+                            "worst_over_tolerance": err, "ok": bool(err <= 1.0)}
+        if err > 1.0:
+            result["value"] = 0.0
+            result["error"] = "parity gate failed"
+
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+/* spectral.h -- C ABI of libspectral.so: MI355X (gfx950) spectral-analysis kernels.
+ *
+ * This is the drop-in boundary underneath the Python modules in pyfft_amd/ that mirror
+ * gmweir/PYFFT's numpy-array function signatures.  The reference has no FFI of its own
+ * (it is pure Python over numpy.fft); each entry point below names the reference call
+ * site(s) whose arithmetic it replaces.  Reference paths are relative to the reference
+ * checkout (file:line).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes only.  Caller owns every buffer.
+ *  - `mem`: 0 = all data pointers are host memory (library stages through its own device
+ *    scratch, synchronously); 1 = all data pointers are device memory on the current
+ *    device (nothing is copied; work is enqueued on the stream set by sp_set_stream and
+ *    the call returns after enqueueing -- small parameter tables (window, filter taps)
+ *    are ALWAYS host pointers.
+ *  - complex = interleaved float re,im (numpy complex64).  Reduced spectra (Welch
+ *    accumulators) are returned in double.
+ *  - return value: 0 = ok, <0 = error; sp_last_error() gives the message (thread-local).
+ *  - one global context per process / one device per process (multi-GPU = one process per
+ *    GPU, torch.distributed/RCCL reduces the accumulators; see pyfft_amd/dist.py).
+ *  - Transform convention (dft.py:108-133, :242-290): forward unnormalised e^{-j2pi nk/N},
+ *    inverse scaled 1/N.
+ */
+#ifndef SPECTRAL_H
+#define SPECTRAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_DTYPE_F32 0 /* real float32 samples    */
+#define SP_DTYPE_C64 1 /* complex64 samples (re,im) */
+
+#define SP_SIDED_ONE 1 /* reference one-sided: bins [0,N/2), x2 on [1:-1] (Nyquist dropped; Q1) */
+#define SP_SIDED_TWO 2 /* two-sided, fftshift-ed                                               */
+#define SP_SIDED_RAW 3 /* two-sided, natural FFT order, no doubling                            */
+
+/* ---- context ------------------------------------------------------------------------ */
+int sp_init(int device_id);          /* select device, create context (idempotent)          */
+void sp_shutdown(void);              /* free plan cache + scratch                           */
+const char *sp_last_error(void);
+int sp_set_stream(void *hip_stream); /* hipStream_t for mem=1 calls (NULL = default stream) */
+int sp_synchronize(void);            /* wait for the library's stream                       */
+int sp_version(void);
+int sp_max_wg_fft(void);             /* largest power-of-two FFT done inside one workgroup  */
+/* Measurement hook: when enabled, the dominant kernel of each Welch call (k_welch) is bracketed by HIP events
+ * recorded on the launch stream; sp_profile_last_ms() waits for them and returns the kernel's duration. */
+int sp_profile_enable(int on);
+int sp_profile_last_ms(double *ms);
+/* device properties used by the host to size grids: out[0]=CU count, out[1]=LDS bytes/CU,
+ * out[2]=clock kHz, out[3]=wavefront size */
+int sp_device_info(int64_t out[4]);
+
+/* ---- A7: fftanal.fft / .ifft  (fft_analysis.py:2096-2116 -> np.fft.fft/ifft) ---------- */
+/* batch x n-point C2C transforms, rows contiguous.  n: any length >= 1 (powers of two up
+ * to sp_max_wg_fft() run in one workgroup; longer powers of two use the multi-pass
+ * four-step path; other lengths use Bluestein's chirp-z on top of those).
+ * direction: -1 forward, +1 inverse (scaled 1/n). in == out allowed. */
+int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int direction, int mem);
+
+/* ---- A3+A4: fftanal.fft_win -> Pstft -> averagewins (fft_analysis.py:2126-2203,
+ *      :1944-1990), the fused Welch PSD: per frame g, X_g = FFT(win * (x[g*hop : g*hop+nfft] - mean));
+ *      pxx[k] = scale/nframes * sum_g |X_g[k]|^2 with the sidedness permutation/doubling.
+ *      mean_re/mean_im: value subtracted from every sample (global detrend, :2148); pass 0,0
+ *      for detrend 'none'.  If `want_mean` != 0 the library computes the mean of x[0:nsig]
+ *      itself (one extra pass) and ignores mean_re/im.
+ *      nbins = nfft/2 for SP_SIDED_ONE (nfft even), nfft otherwise. */
+int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop,
+                 int64_t nframes, int want_mean, double mean_re, double mean_im, int sided,
+                 double scale, double *pxx_out, int mem);
+
+/* ---- A5: fft_pwelch numeric core (fft_analysis.py:339-446): reference x against nch
+ *      channels y[c][0:nsig] (channel-major, row stride y_ld samples).
+ *      pxx[nbins], pyy[nch][nbins], pxy[nch][nbins] complex (re,im doubles) = Y_c * conj(X)
+ *      (function-path conjugation, :393; the class path's X*conj(Y), :1960, is its conjugate).
+ *      means: want_mean as above (per signal); else mean_x / mean_y[nch] are subtracted. */
+int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch, int64_t y_ld,
+                 const float *win, int nfft, int hop, int64_t nframes, int want_mean,
+                 const double *mean_x /*[2]*/, const double *mean_y /*[nch][2]*/, int sided,
+                 double scale, double *pxx, double *pyy, double *pxy, int mem);
+
+/* ---- cfg5: full cross-spectral-density matrix of nch real channels x[c][0:nsig]
+ *      (generalises the ref x channel loop fft_analysis.py:387-393 / HeatPulse_Funcs.py:576-583).
+ *      g_out[nfft/2+1][nch][nch] complex double, = scale/nframes * sum_g X_i conj(X_j), no doubling. */
+int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft,
+                  int hop, int64_t nframes, int want_mean, double scale, double *g_out, int mem);
+
+/* ---- A8/A9: spectrogram.stft -> fftanal.fft_win (spectrogram.py:140-168, fft_analysis.py:2126-2203)
+ *      and spectrogram.specgram (spectrogram.py:91-112).
+ *      out_kind 0: complex64 amp_scale * X_g[k] (sqrt(2) on [1:-1] for SP_SIDED_ONE);
+ *      out_kind 1: float32 power amp_scale * |X_g[k]|^2 (no doubling).
+ *      out_major 0: [nframes][nbins] (fftanal Xseg); 1: [nbins][nframes] (specgram).
+ *      pseg_out (may be NULL): float64[nframes] = trapz(|win*(x-mean)|^2) with unit spacing (:2174; host
+ *      multiplies by dt and divides by S2). */
+int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+            int want_mean, double mean_re, double mean_im, int sided, double amp_scale, int out_kind,
+            int out_major, void *out, double *pseg_out, int mem);
+
+/* ---- A10: hilbert.hilbert / hilbert_1d (hilbert.py:22-112): rows of n_in real samples (row stride
+ *      x_ld), transform length nfft (zero-pad / truncate like np.fft.fft(n=nfft)), one-sided mask with the
+ *      reference's odd-length convention (bin nyq untouched), inverse; out[batch][nfft] complex64. */
+int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t batch, void *out, int mem);
+
+/* ---- A11: ccf.ccf (ccf.py:66-77): normalised cross-covariance of two real length-n signals at all
+ *      2n-1 lags, via zero-padded FFTs; co_out[2n-1] float32 in np.correlate(...,'full') order. */
+int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem);
+
+/* ---- F1 (build-defined; nearest reference code filters.py:282, ccf.py:283): causal FIR
+ *      y = lfilter(h, 1, x)[0:n] by overlap-save with nfft-point blocks (nfft power of two > ntaps;
+ *      0 = choose). */
+int sp_fftfilt(const float *h, int ntaps, const float *x, int64_t n, int nfft, float *y, int mem);
+
+/* ---- helper: mean of a float32 / complex64 vector in double (fft_analysis.py:2148 detrend) */
+int sp_mean(const void *x, int x_dtype, int64_t n, double out[2], int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,264 @@
+"""Array-level entry points over the C ABI (libspectral.so).
+
+Two calling modes, chosen by the type of the sample array:
+  * numpy arrays  -> `mem=0`: the library stages host buffers through its own device scratch and returns
+                     numpy results (synchronous).  This is what the drop-in modules use.
+  * torch CUDA tensors -> `mem=1`: device pointers are passed straight through, work is enqueued on
+                     torch's current stream, results are torch tensors on the same device (asynchronous).
+                     PyTorch is only the allocator / stream owner here.
+There is no CPU implementation behind these functions.
+"""
+import numpy as np
+
+from . import _ffi
+from ._ffi import SIDED_ONE, SIDED_TWO, SIDED_RAW, check, lib, ptr
+
+try:                                    # torch is optional plumbing (device memory + streams)
+    import torch
+except Exception:                       # pragma: no cover
+    torch = None
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+def _bind_stream(x):
+    """mem=1 prologue: make the library launch on torch's current stream for x's device."""
+    if not x.is_cuda:
+        raise TypeError("torch tensors passed to pyfft_amd.engine must live on the GPU")
+    _ffi.init(x.device.index if x.device.index is not None else torch.cuda.current_device())
+    check(lib().sp_set_stream(torch.cuda.current_stream(x.device).cuda_stream))
+
+
+def _torch_samples(x):
+    if x.dtype not in (torch.float32, torch.complex64):
+        raise TypeError("device path takes float32 or complex64 samples, got %s" % x.dtype)
+    return x.contiguous()
+
+
+def _tcode(x):
+    return _ffi.DTYPE_C64 if x.dtype == torch.complex64 else _ffi.DTYPE_F32
+
+
+def _win32(win):
+    return np.ascontiguousarray(np.asarray(win), dtype=np.float32)
+
+
+def nbins(nfft, sided):
+    return nfft // 2 if sided == SIDED_ONE else nfft
+
+
+def max_wg_fft():
+    return int(lib().sp_max_wg_fft())
+
+
+# ------------------------------------------------------------------------------------------ A7
+def fft(x, n=None, axis=-1, inverse=False):
+    """np.fft.fft / ifft semantics (forward unnormalised, inverse 1/n) on the GPU, complex64 math."""
+    if _is_torch(x):
+        _bind_stream(x)
+        if axis not in (-1, x.dim() - 1) or (n is not None and n != x.shape[-1]):
+            raise NotImplementedError("device-tensor fft: last axis, n == length")
+        xc = x.to(torch.complex64).contiguous()
+        out = torch.empty_like(xc)
+        nn = xc.shape[-1]
+        check(lib().sp_fft_c2c(ptr(xc.data_ptr()), ptr(out.data_ptr()), nn, xc.numel() // nn, 1 if inverse else -1, 1))
+        return out
+    a = np.asarray(x)
+    a = np.moveaxis(a, axis, -1)
+    if n is not None and n != a.shape[-1]:
+        if n < a.shape[-1]:
+            a = a[..., :n]
+        else:
+            pad = [(0, 0)] * (a.ndim - 1) + [(0, n - a.shape[-1])]
+            a = np.pad(a, pad)
+    a = np.ascontiguousarray(a, dtype=np.complex64)
+    out = np.empty_like(a)
+    nn = a.shape[-1]
+    _ffi.init()
+    check(lib().sp_fft_c2c(ptr(a), ptr(out), nn, a.size // nn if nn else 0, 1 if inverse else -1, 0))
+    return np.moveaxis(out, -1, axis)
+
+
+def ifft(x, n=None, axis=-1):
+    return fft(x, n=n, axis=axis, inverse=True)
+
+
+# ------------------------------------------------------------------------------------------ A13
+def mean(x):
+    """Mean of a float32/complex64 vector accumulated in double on the device (python float / complex)."""
+    out = (_ffi.C.c_double * 2)()
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = _torch_samples(x)
+        cplx = xs.is_complex()
+        check(lib().sp_mean(ptr(xs.data_ptr()), _tcode(xs), xs.numel(), out, 1))
+    else:
+        xs = _ffi.as_samples(x)
+        cplx = xs.dtype == np.complex64
+        _ffi.init()
+        check(lib().sp_mean(ptr(xs), _ffi.dtype_code(xs.dtype), xs.size, out, 0))
+    return complex(out[0], out[1]) if cplx else float(out[0])
+
+
+def profile_enable(on=True):
+    _ffi.init()
+    check(lib().sp_profile_enable(1 if on else 0))
+
+
+def profile_last_ms():
+    ms = _ffi.C.c_double(0.0)
+    check(lib().sp_profile_last_ms(_ffi.C.byref(ms)))
+    return ms.value
+
+
+# ------------------------------------------------------------------------------------------ A3+A4
+def welch_psd(x, win, hop, nframes, detrend=True, sided=SIDED_TWO, scale=1.0, mean_value=None):
+    """Fused Welch PSD: scale/nframes * sum_g |FFT(win*(x_g - mean))|^2, float64 [nbins].
+    detrend=True subtracts the mean of the whole of x (computed on the device) unless mean_value is given."""
+    w = _win32(win)
+    nfft = w.size
+    nb = nbins(nfft, sided)
+    want = 1 if (detrend and mean_value is None) else 0
+    mv = complex(mean_value) if (detrend and mean_value is not None) else 0j
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = _torch_samples(x)
+        out = torch.empty(nb, dtype=torch.float64, device=xs.device)
+        check(lib().sp_welch_psd(ptr(xs.data_ptr()), _tcode(xs), xs.numel(), ptr(w), nfft, int(hop), int(nframes), want,
+                                 mv.real, mv.imag, sided, float(scale), ptr(out.data_ptr()), 1))
+        return out
+    xs = _ffi.as_samples(x)
+    out = np.empty(nb, dtype=np.float64)
+    _ffi.init()
+    check(lib().sp_welch_psd(ptr(xs), _ffi.dtype_code(xs.dtype), xs.size, ptr(w), nfft, int(hop), int(nframes), want,
+                             mv.real, mv.imag, sided, float(scale), ptr(out), 0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ A5
+def welch_csd(x, y, win, hop, nframes, detrend=True, sided=SIDED_ONE, scale=1.0):
+    """Reference signal x[nsig] against channels y[nch, nsig] (channel-major).
+    Returns (Pxx[nb], Pyy[nch, nb], Pxy[nch, nb] complex128 = Y conj(X)), all float64 based."""
+    w = _win32(win)
+    nfft = w.size
+    nb = nbins(nfft, sided)
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = _torch_samples(x)
+        ys = _torch_samples(y)
+        if ys.dim() == 1:
+            ys = ys[None, :]
+        nch, ld = ys.shape
+        pxx = torch.empty(nb, dtype=torch.float64, device=xs.device)
+        pyy = torch.empty((nch, nb), dtype=torch.float64, device=xs.device)
+        pxy = torch.empty((nch, nb), dtype=torch.complex128, device=xs.device)
+        check(lib().sp_welch_csd(ptr(xs.data_ptr()), ptr(ys.data_ptr()), _tcode(xs), xs.numel(), nch, ld, ptr(w), nfft,
+                                 int(hop), int(nframes), 1 if detrend else 0, None, None, sided, float(scale),
+                                 ptr(pxx.data_ptr()), ptr(pyy.data_ptr()), ptr(pxy.data_ptr()), 1))
+        return pxx, pyy, pxy
+    xs = _ffi.as_samples(x)
+    ys = np.asarray(y)
+    if ys.ndim == 1:
+        ys = ys[None, :]
+    ys = np.ascontiguousarray(ys, dtype=xs.dtype)
+    if np.iscomplexobj(y) and xs.dtype != np.complex64:
+        xs = xs.astype(np.complex64)
+        ys = np.ascontiguousarray(y, dtype=np.complex64).reshape(ys.shape)
+    nch, ld = ys.shape
+    pxx = np.empty(nb, dtype=np.float64)
+    pyy = np.empty((nch, nb), dtype=np.float64)
+    pxy = np.empty((nch, nb), dtype=np.complex128)
+    _ffi.init()
+    check(lib().sp_welch_csd(ptr(xs), ptr(ys), _ffi.dtype_code(xs.dtype), xs.size, nch, ld, ptr(w), nfft, int(hop),
+                             int(nframes), 1 if detrend else 0, None, None, sided, float(scale), ptr(pxx), ptr(pyy),
+                             ptr(pxy), 0))
+    return pxx, pyy, pxy
+
+
+# ------------------------------------------------------------------------------------------ A8/A9
+def stft_frames(x, win, hop, nframes, detrend=True, sided=SIDED_ONE, amp_scale=1.0, power=False, bin_major=False,
+                want_pseg=False, mean_value=None):
+    """Per-frame spectra.  complex64 [nframes, nbins] (or float32 power); bin_major -> [nbins, nframes].
+    Returns (out, pseg or None); pseg[g] = trapz(|win*(x_g-mean)|^2), unit sample spacing, float64."""
+    w = _win32(win)
+    nfft = w.size
+    nb = nbins(nfft, sided)
+    want = 1 if (detrend and mean_value is None) else 0
+    mv = complex(mean_value) if (detrend and mean_value is not None) else 0j
+    shape = (nb, int(nframes)) if bin_major else (int(nframes), nb)
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = _torch_samples(x)
+        out = torch.empty(shape, dtype=torch.float32 if power else torch.complex64, device=xs.device)
+        pseg = torch.empty(int(nframes), dtype=torch.float64, device=xs.device) if want_pseg else None
+        check(lib().sp_stft(ptr(xs.data_ptr()), _tcode(xs), xs.numel(), ptr(w), nfft, int(hop), int(nframes), want,
+                            mv.real, mv.imag, sided, float(amp_scale), 1 if power else 0, 1 if bin_major else 0,
+                            ptr(out.data_ptr()), ptr(pseg.data_ptr()) if want_pseg else None, 1))
+        return out, pseg
+    xs = _ffi.as_samples(x)
+    out = np.empty(shape, dtype=np.float32 if power else np.complex64)
+    pseg = np.empty(int(nframes), dtype=np.float64) if want_pseg else None
+    _ffi.init()
+    check(lib().sp_stft(ptr(xs), _ffi.dtype_code(xs.dtype), xs.size, ptr(w), nfft, int(hop), int(nframes), want,
+                        mv.real, mv.imag, sided, float(amp_scale), 1 if power else 0, 1 if bin_major else 0, ptr(out),
+                        ptr(pseg), 0))
+    return out, pseg
+
+
+# ------------------------------------------------------------------------------------------ A10
+def hilbert_rows(x2d, nfft):
+    """Analytic signal of each row of a real [batch, n_in] array, transform length nfft -> complex64 [batch, nfft]."""
+    if _is_torch(x2d):
+        _bind_stream(x2d)
+        xs = x2d.to(torch.float32).contiguous()
+        batch, n_in = xs.shape
+        out = torch.empty((batch, nfft), dtype=torch.complex64, device=xs.device)
+        check(lib().sp_hilbert(ptr(xs.data_ptr()), n_in, n_in, int(nfft), batch, ptr(out.data_ptr()), 1))
+        return out
+    xs = np.ascontiguousarray(x2d, dtype=np.float32)
+    batch, n_in = xs.shape
+    out = np.empty((batch, nfft), dtype=np.complex64)
+    _ffi.init()
+    check(lib().sp_hilbert(ptr(xs), n_in, n_in, int(nfft), batch, ptr(out), 0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ A11
+def xcorr_normalised(x1, x2):
+    """co[2n-1] = correlate(x1-m1, x2-m2, 'full') / (n std1 std2), float32."""
+    if _is_torch(x1):
+        _bind_stream(x1)
+        a = x1.to(torch.float32).contiguous()
+        b = x2.to(torch.float32).contiguous()
+        n = a.numel()
+        out = torch.empty(2 * n - 1, dtype=torch.float32, device=a.device)
+        check(lib().sp_xcorr(ptr(a.data_ptr()), ptr(b.data_ptr()), n, ptr(out.data_ptr()), 1))
+        return out
+    a = np.ascontiguousarray(x1, dtype=np.float32)
+    b = np.ascontiguousarray(x2, dtype=np.float32)
+    if a.shape != b.shape or a.ndim != 1:
+        raise ValueError("xcorr: two 1-D signals of equal length")
+    n = a.size
+    out = np.empty(2 * n - 1, dtype=np.float32)
+    _ffi.init()
+    check(lib().sp_xcorr(ptr(a), ptr(b), n, ptr(out), 0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ F1
+def fir_filter(h, x, nfft=0):
+    """Causal FIR y = lfilter(h, 1, x) (float32) by overlap-save on the GPU."""
+    taps = np.ascontiguousarray(h, dtype=np.float32)
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = x.to(torch.float32).contiguous()
+        out = torch.empty_like(xs)
+        check(lib().sp_fftfilt(ptr(taps), taps.size, ptr(xs.data_ptr()), xs.numel(), int(nfft), ptr(out.data_ptr()), 1))
+        return out
+    xs = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(xs)
+    _ffi.init()
+    check(lib().sp_fftfilt(ptr(taps), taps.size, ptr(xs), xs.size, int(nfft), ptr(out), 0))
+    return out

@@ -1,0 +1,253 @@
+"""GPU parity of the HIP kernels (through the C ABI, via pyfft_amd.engine) against the CPU oracle on the same
+seeded inputs and against the committed golden fixtures.  float32 device math vs float64 oracle:
+tolerances are the ones BASELINE.md / SURVEY.md section 8d state, written next to each check."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpu_ref as O
+
+
+@pytest.fixture(scope="module")
+def E():
+    from pyfft_amd import engine
+    from pyfft_amd import _ffi
+    _ffi.init()
+    return engine
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+
+
+# ---------------------------------------------------------------- A7 batched FFT
+@pytest.mark.parametrize("n", [2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048, 4096, 8192])
+def test_fft_forward_inverse(E, n):
+    rng = np.random.default_rng(n)
+    batch = 37 if n <= 1024 else 5
+    x = (rng.standard_normal((batch, n)) + 1j * rng.standard_normal((batch, n))).astype(np.complex64)
+    X = E.fft(x)
+    ref = np.fft.fft(x.astype(np.complex128), axis=-1)
+    # forward vs float64: <= 2e-6*sqrt(log2 N) relative to ||X||_inf
+    assert relerr(X, ref) <= 2e-6 * max(1.0, np.sqrt(np.log2(n)))
+    xr = E.ifft(X)
+    # round trip: max|ifft(fft(x)) - x| / max|x| <= 5e-6
+    assert relerr(xr, x) <= 5e-6
+    # inverse alone vs float64
+    assert relerr(E.ifft(x), np.fft.ifft(x.astype(np.complex128), axis=-1)) <= 2e-6 * max(1.0, np.sqrt(np.log2(n)))
+
+
+def test_fft_linearity_and_impulse(E):
+    n = 4096
+    x = np.zeros((3, n), dtype=np.complex64)
+    x[0, 0] = 1.0          # impulse -> all ones
+    x[1, 1] = 1.0          # shifted impulse -> exp(-2 pi i k/N)
+    x[2, :] = 1.0          # constant -> N delta
+    X = E.fft(x)
+    k = np.arange(n)
+    assert np.max(np.abs(X[0] - 1.0)) < 1e-6
+    assert np.max(np.abs(X[1] - np.exp(-2j * np.pi * k / n))) < 2e-6
+    assert abs(X[2, 0] - n) < 1e-2 and np.max(np.abs(X[2, 1:])) < 1e-2
+
+
+def test_fft_axis_and_pad(E):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((64, 6)).astype(np.float32)
+    X = E.fft(x, n=128, axis=0)
+    assert relerr(X, np.fft.fft(x.astype(np.float64), n=128, axis=0)) < 5e-6
+
+
+# ---------------------------------------------------------------- A3+A4 Welch PSD (class path)
+@pytest.mark.parametrize("tag", ["c64_2e16_n4096", "c64_2e14_n1024"])
+def test_welch_psd_golden_complex(E, tag):
+    g = load_golden("welch_class_" + tag)
+    x = g["x"]
+    nfft, nov, M = int(g["nwins"]), int(g["noverlap"]), int(g["Navr"])
+    win = O.windows("Hanning", nwins=nfft)
+    scale = 1.0 / (float(g["Fs"]) * float(g["S2"]))
+    P = E.welch_psd(x, win, nfft - nov, M, detrend=True, sided=E.SIDED_TWO, scale=scale)
+    ref = g["Pxx"].real
+    # Welch PSD bins: rtol 2e-4, atol 1e-6*max(Pxx)
+    np.testing.assert_allclose(P, ref, rtol=2e-4, atol=1e-6 * ref.max())
+    # natural-order variant is the un-shifted spectrum
+    Praw = E.welch_psd(x, win, nfft - nov, M, detrend=True, sided=E.SIDED_RAW, scale=scale)
+    np.testing.assert_allclose(np.fft.fftshift(Praw), P, rtol=1e-12)
+    # detrend off + explicit mean
+    P0 = E.welch_psd(x, win, nfft - nov, M, detrend=False, sided=E.SIDED_TWO, scale=scale)
+    ref0 = O.welch_psd_stream(x, win, nfft, nfft - nov, M, float(g["Fs"]), detrend_style=0)
+    np.testing.assert_allclose(P0, ref0, rtol=2e-4, atol=1e-6 * ref0.max())
+    Pm = E.welch_psd(x, win, nfft - nov, M, detrend=True, sided=E.SIDED_TWO, scale=scale,
+                     mean_value=complex(x.astype(np.complex128).mean()))
+    np.testing.assert_allclose(Pm, ref, rtol=2e-4, atol=1e-6 * ref.max())
+
+
+@pytest.mark.parametrize("wname", ["Hamming"])
+def test_welch_psd_real_onesided(E, wname):
+    g = load_golden("welch_class_real_" + wname)
+    x = g["x"]
+    nfft, nov, M = int(g["nwins"]), int(g["noverlap"]), int(g["Navr"])
+    if nfft & (nfft - 1):
+        pytest.skip("non power-of-two nwins=%d (Bluestein path)" % nfft)
+    win = O.windows(wname, nwins=nfft)
+    S2 = np.sum(win ** 2)
+    P = E.welch_psd(x, win, nfft - nov, M, detrend=True, sided=E.SIDED_ONE, scale=1.0 / (float(g["Fs"]) * S2))
+    ref = g["Pxx"].real
+    np.testing.assert_allclose(P, ref, rtol=2e-4, atol=1e-6 * ref.max())
+
+
+@pytest.mark.parametrize("nfft,hop", [(64, 16), (256, 256), (512, 100), (2048, 512), (8192, 4096), (1024, 1)])
+def test_welch_psd_shapes(E, nfft, hop):
+    """ragged run partition, hop that is not a divisor, single frame, real and complex input."""
+    rng = np.random.default_rng(nfft + hop)
+    nsig = nfft + hop * 37 + 5
+    for cplx in (False, True):
+        x = rng.standard_normal(nsig) + (1j * rng.standard_normal(nsig) if cplx else 0) + 0.5
+        x = x.astype(np.complex64 if cplx else np.float32)
+        M = (nsig - nfft) // hop + 1
+        win = O.windows("Nuttall4c", nwins=nfft)
+        for frames in (M, 1):
+            P = E.welch_psd(x, win, hop, frames, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+            ref = O.welch_psd_stream(x, win, nfft, hop, frames, 1.0) * np.sum(win ** 2)
+            np.testing.assert_allclose(P, ref, rtol=2e-4, atol=2e-6 * ref.max())
+
+
+def test_welch_errors(E):
+    from pyfft_amd._ffi import SpectralError
+    x = np.zeros(1000, dtype=np.float32)
+    with pytest.raises(SpectralError):
+        E.welch_psd(x, np.ones(512), 256, 10)            # frames run past the signal
+
+
+# ---------------------------------------------------------------- A5 fft_pwelch core
+def test_welch_csd_cfg1(E):
+    g = load_golden("pwelch_cfg1")
+    t, x, y = g["t"], g["x"], g["y"]
+    i0, i1 = [int(v) for v in g["info_ibnds"]]
+    nfft, nov, M = int(g["info_nwins"]), int(g["info_noverlap"]), int(g["info_Navr"])
+    win = O.windows("Hanning", nwins=nfft)
+    scale = 1.0 / (float(g["info_Fs"]) * float(g["info_S2"]))
+    pxx, pyy, pxy = E.welch_csd(x[i0:i1], y[i0:i1][None, :], win, nfft - nov, M, detrend=True, sided=E.SIDED_ONE,
+                                scale=scale)
+    np.testing.assert_allclose(pxx, g["Pxx"].real, rtol=2e-4, atol=1e-6 * g["Pxx"].real.max())
+    np.testing.assert_allclose(pyy[0], g["Pyy"].real, rtol=2e-4, atol=1e-6 * g["Pyy"].real.max())
+    np.testing.assert_allclose(pxy[0], g["Pxy"], rtol=2e-4, atol=1e-6 * np.abs(g["Pxy"]).max())
+
+
+def test_welch_csd_multichannel_twosided(E):
+    rng = np.random.default_rng(77)
+    n, nfft, hop = 20000, 512, 256
+    k = np.arange(n)
+    x = (np.sin(0.3 * k) + 0.2 * rng.standard_normal(n) + 1.0).astype(np.float32)
+    y = np.stack([0.5 * np.sin(0.3 * k - 0.7) + 0.1 * rng.standard_normal(n),
+                  rng.standard_normal(n) - 2.0,
+                  0.25 * x + 0.1 * rng.standard_normal(n)]).astype(np.float32)
+    M = (n - nfft) // hop + 1
+    win = O.windows("Hamming", nwins=nfft)
+    pxx, pyy, pxy = E.welch_csd(x, y, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+    xd = x.astype(np.float64) - x.astype(np.float64).mean()
+    yd = y.astype(np.float64) - y.astype(np.float64).mean(axis=1, keepdims=True)
+    idx = (np.arange(M) * hop)[:, None] + np.arange(nfft)[None, :]
+    X = np.fft.fftshift(np.fft.fft(win * xd[idx], axis=-1), axes=-1)
+    np.testing.assert_allclose(pxx, (np.abs(X) ** 2).mean(axis=0), rtol=2e-4, atol=1e-6 * (np.abs(X) ** 2).mean(axis=0).max())
+    for c in range(3):
+        Y = np.fft.fftshift(np.fft.fft(win * yd[c][idx], axis=-1), axes=-1)
+        ryy = (np.abs(Y) ** 2).mean(axis=0)
+        rxy = (Y * np.conj(X)).mean(axis=0)
+        np.testing.assert_allclose(pyy[c], ryy, rtol=2e-4, atol=1e-6 * ryy.max())
+        np.testing.assert_allclose(pxy[c], rxy, rtol=2e-4, atol=2e-6 * np.abs(rxy).max())
+
+
+# ---------------------------------------------------------------- A8/A9 STFT / specgram
+def test_stft_golden_f32(E):
+    g = load_golden("stft_f32_n2048_ov75")
+    x = g["x"]
+    nfft, nov, M, Fs = int(g["nwins"]), int(g["noverlap"]), int(g["Navr"]), float(g["Fs"])
+    win = O.windows("Hanning", nwins=nfft)
+    S1, S2 = win.sum(), (win ** 2).sum()
+    amp = 1.0 / (S1 * np.sqrt(Fs * S2 / S1 ** 2))
+    Xseg, pseg = E.stft_frames(x, win, nfft - nov, M, detrend=True, sided=E.SIDED_ONE, amp_scale=amp, want_pseg=True)
+    assert Xseg.shape == (M, nfft // 2)
+    scale = np.abs(g["Xseg_head"]).max()
+    # STFT: rtol 1e-4 relative to ||.||_inf
+    assert np.max(np.abs(Xseg[:3] - g["Xseg_head"])) <= 1e-4 * scale
+    assert np.max(np.abs(Xseg[M // 2:M // 2 + 2] - g["Xseg_mid"])) <= 1e-4 * scale
+    assert np.max(np.abs(Xseg[-2:] - g["Xseg_tail"])) <= 1e-4 * scale
+    # Xpow = trapz(|w x|^2, t)/S2 with dt = 1/Fs
+    np.testing.assert_allclose(pseg / Fs / S2, g["Xpow"], rtol=1e-4)
+    # mean |Xseg|^2 == Pxx
+    P = (np.abs(Xseg.astype(np.complex128)) ** 2).mean(axis=0)
+    np.testing.assert_allclose(P, g["Pxx"].real, rtol=3e-4, atol=1e-6 * g["Pxx"].real.max())
+
+
+def test_stft_twosided_complex_and_power_binmajor(E):
+    g = load_golden("welch_class_c64_2e16_n4096")
+    x = g["x"]
+    nfft, nov, M, Fs = int(g["nwins"]), int(g["noverlap"]), int(g["Navr"]), float(g["Fs"])
+    win = O.windows("Hanning", nwins=nfft)
+    amp = 1.0 / np.sqrt(Fs * float(g["S2"]))
+    Xseg, _ = E.stft_frames(x, win, nfft - nov, M, detrend=True, sided=E.SIDED_TWO, amp_scale=amp)
+    scale = np.abs(g["Xseg_head"]).max()
+    assert np.max(np.abs(Xseg[:4] - g["Xseg_head"])) <= 1e-4 * scale
+    assert np.max(np.abs(Xseg[-2:] - g["Xseg_tail"])) <= 1e-4 * scale
+    # specgram-style output: power, natural order, [bins, frames]
+    s = load_golden("specgram")
+    sig, wl = s["s"], 512
+    nW = s["sp1"].shape[1]
+    out, _ = E.stft_frames(sig, np.hanning(wl), wl // 2, nW, detrend=False, sided=E.SIDED_RAW,
+                           amp_scale=np.sqrt(8.0 / 3.0) / wl, power=True, bin_major=True)
+    assert out.shape == s["sp1"].shape
+    np.testing.assert_allclose(out, s["sp1"], rtol=2e-4, atol=1e-6 * s["sp1"].max())
+
+
+# ---------------------------------------------------------------- A10 hilbert
+def test_hilbert_rows(E):
+    g = load_golden("hilbert")
+    z = E.hilbert_rows(g["u_even"][None, :], 4096)[0]
+    assert np.max(np.abs(z - g["z_even"])) <= 1e-4 * np.abs(g["z_even"]).max()
+    z2 = E.hilbert_rows(g["u_2d"], 512)
+    assert np.max(np.abs(z2 - g["z_2d"])) <= 1e-4 * np.abs(g["z_2d"]).max()
+    zk = E.hilbert_rows(g["yk"][None, :], 32)[0]
+    ph = 2 * np.pi * np.arange(32) / 32
+    assert np.max(np.abs(zk - (np.sin(ph) - 1j * np.cos(ph)))) < 2e-6      # hilbert.py:115-140 KAT
+    zp = E.hilbert_rows(g["u_even"][None, :1000], 1024)[0]                    # zero-padded transform length
+    assert np.max(np.abs(zp - g["z_nfft"])) <= 1e-4 * np.abs(g["z_nfft"]).max()
+    # real part of the analytic signal is the input
+    assert np.max(np.abs(z.real - g["u_even"])) < 1e-5 * np.abs(g["u_even"]).max()
+
+
+# ---------------------------------------------------------------- A11 ccf
+def test_xcorr_golden(E):
+    g = load_golden("ccf")
+    co = E.xcorr_normalised(g["x1"], g["x2"])
+    assert co.shape == g["co"].shape
+    assert np.max(np.abs(co - g["co"])) <= 1e-4 * np.abs(g["co"]).max()
+    co2 = E.xcorr_normalised(g["x3"], g["x4"])         # odd length 777, non-zero mean
+    assert np.max(np.abs(co2 - g["co2"])) <= 1e-4 * np.abs(g["co2"]).max()
+    # autocorrelation: symmetric, 1 at zero lag
+    a = E.xcorr_normalised(g["x1"], g["x1"])
+    n = g["x1"].size
+    assert abs(a[n - 1] - 1.0) < 1e-5 and np.max(np.abs(a - a[::-1])) < 1e-5
+
+
+# ---------------------------------------------------------------- F1 FIR
+@pytest.mark.parametrize("ntaps,n,nfft", [(513, 40000, 4096), (513, 40000, 0), (31, 5000, 1024), (2, 100, 64),
+                                           (1, 1000, 256), (4097, 20000, 8192)])
+def test_fir_filter(E, ntaps, n, nfft):
+    rng = np.random.default_rng(ntaps + n)
+    h = rng.standard_normal(ntaps) / np.sqrt(ntaps)
+    x = rng.standard_normal(n)
+    y = E.fir_filter(h, x, nfft=nfft)
+    ref = O.fftfilt(h.astype(np.float32).astype(np.float64), x.astype(np.float32).astype(np.float64))
+    assert y.shape == ref.shape
+    assert np.max(np.abs(y - ref)) <= 1e-4 * np.abs(ref).max()
+
+
+def test_mean(E):
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal(100001) + 3.0).astype(np.float32)
+    assert abs(E.mean(x) - x.astype(np.float64).mean()) < 1e-9
+    z = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000) + (1 - 2j)).astype(np.complex64)
+    assert abs(E.mean(z) - z.astype(np.complex128).mean()) < 1e-9
