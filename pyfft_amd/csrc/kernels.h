@@ -56,12 +56,12 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_c2c(const cf *__restrict__
     for (int64_t b0 = (int64_t)blockIdx.x * C::FPW; b0 < batch; b0 += stride) {
         const int64_t b = b0 + grp;
         const bool act = b < batch;
+        const int64_t bl = act ? b : batch - 1;          // clamped: loads stay unconditional
         cf v[C::R];
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) {
-            cf a = act ? in[b * N + tid + C::T * t] : mk(0.f, 0.f);
-            v[t] = mk(a.x, sgn * a.y);
-        }
+        for (int t = 0; t < C::R; ++t) v[t] = in[bl * N + tid + C::T * t];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, sgn * v[t].y);
         f.template run<true>(v, lds, lds, tid);
         if (act) {
 #pragma unroll
@@ -99,33 +99,48 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch(const void *__restrict__
     const int64_t g0 = gid * fpg;
     for (int64_t i = 0; i < fpg; ++i) {
         const int64_t g = g0 + i;
-        const bool act = g < nframes;
+        // frames past the end are clamped to the last one and weighted 0: every load is unconditional
+        // (a per-load predicate makes hipcc branch around each load and serialise the round trips)
+        const float keep = g < nframes ? 1.f : 0.f;
+        const int64_t base = (g < nframes ? g : nframes - 1) * hop + tid;
         cf v[C::R];
-        const int64_t base = g * hop + tid;
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) {
-            cf a = act ? load_sample(x, base + C::T * t, CPLX) : mu;
-            v[t] = w[t] * (a - mu);
-        }
+        for (int t = 0; t < C::R; ++t) v[t] = load_sample(x, base + C::T * t, CPLX);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = w[t] * (v[t] - mu);
         f.template run<true>(v, lds, lds, tid);
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) acc[t] += cnorm(v[t]);
+        for (int t = 0; t < C::R; ++t) acc[t] += keep * cnorm(v[t]);
     }
 #pragma unroll
     for (int t = 0; t < C::R; ++t) partial[gid * N + tid + C::T * t] = acc[t];
 }
 
-// sum partial[G][N] over G in double, apply sidedness + scale -> out[nbins] (double)
+// sum partial[G][N] over G in double, apply sidedness + scale -> out[nbins] (double).
+// block = 64 bins x 16 slices of the group range (1024 threads); deterministic order.
+#define SP_FIN_BINS 64
+#define SP_FIN_SLICES 16
 template <int N>
-__global__ void k_welch_finish(const float *__restrict__ partial, int64_t G, int sided, double scale,
-                               double *__restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
-    const int slot = bin_slot<N>(k, sided);
-    if (slot < 0) return;
+__global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_welch_finish(const float *__restrict__ partial, int64_t G,
+                                                                              int sided, double scale,
+                                                                              double *__restrict__ out) {
+    __shared__ double sh[SP_FIN_SLICES][SP_FIN_BINS];
+    const int lane = threadIdx.x % SP_FIN_BINS, sl = threadIdx.x / SP_FIN_BINS;
+    const int k = blockIdx.x * SP_FIN_BINS + lane;
     double s = 0.0;
-    for (int64_t g = 0; g < G; ++g) s += (double)partial[g * N + k];
-    out[slot] = s * scale * (bin_doubled<N>(k, sided) ? 2.0 : 1.0);
+    if (k < N)
+        for (int64_t g = sl; g < G; g += SP_FIN_SLICES) s += (double)partial[g * N + k];
+    sh[sl][lane] = s;
+    __syncthreads();
+    if (sl == 0 && k < N) {
+        const int slot = bin_slot<N>(k, sided);
+        if (slot >= 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int j = 0; j < SP_FIN_SLICES; ++j) tot += sh[j][lane];
+            out[slot] = tot * scale * (bin_doubled<N>(k, sided) ? 2.0 : 1.0);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -163,24 +178,27 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd(const void *__restri
     const int64_t g0 = gid * fpg;
     for (int64_t i = 0; i < fpg; ++i) {
         const int64_t g = g0 + i;
-        const bool act = g < nframes;
-        const int64_t base = g * hop + tid;
+        const float keep = g < nframes ? 1.f : 0.f;
+        const int64_t base = (g < nframes ? g : nframes - 1) * hop + tid;
         cf vx[C::R], vy[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
-            cf a = act ? load_sample(x, base + C::T * t, CPLX) : mux;
-            cf b = act ? load_sample(y, yoff + base + C::T * t, CPLX) : muy;
-            vx[t] = w[t] * (a - mux);
-            vy[t] = w[t] * (b - muy);
+            vx[t] = load_sample(x, base + C::T * t, CPLX);
+            vy[t] = load_sample(y, yoff + base + C::T * t, CPLX);
+        }
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            vx[t] = w[t] * (vx[t] - mux);
+            vy[t] = w[t] * (vy[t] - muy);
         }
         f.template run<true>(vx, lds, lds, tid);
         f.template run<true>(vy, lds, lds, tid);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
-            axx[t] += cnorm(vx[t]);
-            ayy[t] += cnorm(vy[t]);
+            axx[t] += keep * cnorm(vx[t]);
+            ayy[t] += keep * cnorm(vy[t]);
             cf p = cmulc(vy[t], vx[t]);     // Y conj(X)  (fft_analysis.py:393)
-            axy[t] = axy[t] + p;
+            axy[t] = axy[t] + keep * p;
         }
     }
     float *p = partial + ((int64_t)ch * groups_total + gid) * 4 * N;
@@ -196,25 +214,41 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd(const void *__restri
 
 // out layouts: pxx[nbins] (from channel 0's copy), pyy[nch][nbins], pxy[nch][nbins][2]
 template <int N>
-__global__ void k_csd_finish(const float *__restrict__ partial, int64_t G, int nch, int sided, double scale,
-                             double *__restrict__ pxx, double *__restrict__ pyy, double *__restrict__ pxy) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_finish(const float *__restrict__ partial, int64_t G,
+                                                                            int nch, int sided, double scale,
+                                                                            double *__restrict__ pxx,
+                                                                            double *__restrict__ pyy,
+                                                                            double *__restrict__ pxy) {
+    __shared__ double sh[4][SP_FIN_SLICES][SP_FIN_BINS];
+    const int lane = threadIdx.x % SP_FIN_BINS, sl = threadIdx.x / SP_FIN_BINS;
+    const int k = blockIdx.x * SP_FIN_BINS + lane;
     const int ch = blockIdx.y;
-    if (k >= N) return;
-    const int slot = bin_slot<N>(k, sided);
-    if (slot < 0) return;
     const int nb = sided == SIDED_ONE ? N / 2 : N;
     double s[4] = {0, 0, 0, 0};
     const float *p = partial + (int64_t)ch * G * 4 * N;
-    for (int64_t g = 0; g < G; ++g) {
+    if (k < N)
+        for (int64_t g = sl; g < G; g += SP_FIN_SLICES) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) s[j] += (double)p[(g * 4 + j) * N + k];
+            for (int j = 0; j < 4; ++j) s[j] += (double)p[(g * 4 + j) * N + k];
+        }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[j][sl][lane] = s[j];
+    __syncthreads();
+    if (sl == 0 && k < N) {
+        const int slot = bin_slot<N>(k, sided);
+        if (slot >= 0) {
+            double tot[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < SP_FIN_SLICES; ++q) tot[j] += sh[j][q][lane];
+            const double m = scale * (bin_doubled<N>(k, sided) ? 2.0 : 1.0);
+            if (ch == 0) pxx[slot] = tot[0] * m;
+            pyy[(int64_t)ch * nb + slot] = tot[1] * m;
+            pxy[((int64_t)ch * nb + slot) * 2] = tot[2] * m;
+            pxy[((int64_t)ch * nb + slot) * 2 + 1] = tot[3] * m;
+        }
     }
-    const double m = scale * (bin_doubled<N>(k, sided) ? 2.0 : 1.0);
-    if (ch == 0) pxx[slot] = s[0] * m;
-    pyy[(int64_t)ch * nb + slot] = s[1] * m;
-    pxy[((int64_t)ch * nb + slot) * 2] = s[2] * m;
-    pxy[((int64_t)ch * nb + slot) * 2 + 1] = s[3] * m;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -245,13 +279,14 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft(const void *__restrict__ 
     for (int64_t i = 0; i < fpg; ++i) {
         const int64_t g = g0 + i;
         const bool act = g < nframes;
-        const int64_t base = g * hop + tid;
+        const int64_t base = (act ? g : nframes - 1) * hop + tid;
         cf v[C::R];
         float pw = 0.f;
 #pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = load_sample(x, base + C::T * t, CPLX);
+#pragma unroll
         for (int t = 0; t < C::R; ++t) {
-            cf a = act ? load_sample(x, base + C::T * t, CPLX) : mu;
-            v[t] = w[t] * (a - mu);
+            v[t] = w[t] * (v[t] - mu);
             const int n = tid + C::T * t;
             pw += ((n == 0 || n == N - 1) ? 0.5f : 1.f) * cnorm(v[t]);
         }
@@ -310,11 +345,13 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_hilbert(const float *__restric
     for (int64_t b0 = (int64_t)blockIdx.x * C::FPW; b0 < batch; b0 += stride) {
         const int64_t b = b0 + grp;
         const bool act = b < batch;
+        const int64_t bl = act ? b : batch - 1;
         cf v[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int n = tid + C::T * t;
-            v[t] = mk((act && n < n_in) ? x[b * x_ld + n] : 0.f, 0.f);
+            const float a = x[bl * x_ld + (n < n_in ? n : n_in - 1)];     // clamped, unconditional
+            v[t] = mk(n < n_in ? a : 0.f, 0.f);
         }
         f.template run<true>(v, lds, lds, tid);
 #pragma unroll
@@ -364,9 +401,9 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fftfilt(const float *__restric
         for (int t = 0; t < C::R; ++t) {
             const int m = tid + C::T * t;
             const int64_t i0 = s0 + m, i1 = s1 + m;
-            const float a = (act && i0 >= 0 && i0 < n) ? x[i0] : 0.f;
-            const float b = (act && i1 >= 0 && i1 < n) ? x[i1] : 0.f;
-            v[t] = mk(a, b);
+            const bool in0 = act && i0 >= 0 && i0 < n, in1 = act && i1 >= 0 && i1 < n;
+            const float a = x[in0 ? i0 : 0], b = x[in1 ? i1 : 0];      // clamped, unconditional
+            v[t] = mk(in0 ? a : 0.f, in1 ? b : 0.f);
         }
         f.template run<true>(v, lds, lds, tid);
 #pragma unroll
@@ -410,7 +447,9 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_xcorr(const float *__restrict_
 #pragma unroll
     for (int t = 0; t < C::R; ++t) {
         const int i = tid + C::T * t;
-        v[t] = (act && i < n) ? mk(x1[i] - m1, x2[i] - m2) : mk(0.f, 0.f);
+        const bool in = act && i < n;
+        const float a = x1[in ? i : 0], b = x2[in ? i : 0];
+        v[t] = in ? mk(a - m1, b - m2) : mk(0.f, 0.f);
     }
     f.template run<true>(v, lds, lds, tid);
     // mirror exchange: Z[(N-k)%N]
@@ -473,22 +512,35 @@ __global__ void k_moments_partial(const void *__restrict__ x, int64_t n, double 
     }
 }
 
-// one block: out_d[0..1] = mean (double), out_d[2] = sum|x|^2, out_f[0..1] = mean (float, in-dtype rounding)
+// one block of 256: out_d[0..1] = mean (double), out_d[2] = sum|x|^2, out_f[0..1] = mean (float)
 __global__ void k_moments_finish(const double *__restrict__ partial, int nblocks, int64_t n,
                                  double *__restrict__ out_d, float *__restrict__ out_f) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s0 = 0, s1 = 0, s2 = 0;
-        for (int b = 0; b < nblocks; ++b) {
-            s0 += partial[b * 4];
-            s1 += partial[b * 4 + 1];
-            s2 += partial[b * 4 + 2];
+    __shared__ double sh[3][256];
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
+        s0 += partial[b * 4];
+        s1 += partial[b * 4 + 1];
+        s2 += partial[b * 4 + 2];
+    }
+    sh[0][threadIdx.x] = s0;
+    sh[1][threadIdx.x] = s1;
+    sh[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+            sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
         }
-        out_d[0] = s0 / (double)n;
-        out_d[1] = s1 / (double)n;
-        out_d[2] = s2;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_d[0] = sh[0][0] / (double)n;
+        out_d[1] = sh[1][0] / (double)n;
+        out_d[2] = sh[2][0];
         if (out_f) {
-            out_f[0] = (float)(s0 / (double)n);
-            out_f[1] = (float)(s1 / (double)n);
+            out_f[0] = (float)(sh[0][0] / (double)n);
+            out_f[1] = (float)(sh[1][0] / (double)n);
         }
     }
 }

@@ -185,7 +185,7 @@ int dev_moments(const void *x, int dtype, int64_t n, double *out_d /*[4] dev*/, 
         hipLaunchKernelGGL((k_moments_partial<true>), dim3((int)nb), dim3(threads), 0, g.stream, x, n, partial);
     else
         hipLaunchKernelGGL((k_moments_partial<false>), dim3((int)nb), dim3(threads), 0, g.stream, x, n, partial);
-    hipLaunchKernelGGL(k_moments_finish, dim3(1), dim3(64), 0, g.stream, partial, (int)nb, n, out_d, out_f);
+    hipLaunchKernelGGL(k_moments_finish, dim3(1), dim3(256), 0, g.stream, partial, (int)nb, n, out_d, out_f);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -228,7 +228,8 @@ int dev_welch_psd(const void *x, int dtype, const float *win_d, int nfft, int ho
                 hipLaunchKernelGGL((k_welch<NN, false>), dim3(blocks), dim3(C::WG), C::lds_bytes(1), g.stream, x, \
                                    win_d, hop, nframes, fpg, mean_d, tw, partial);                   \
         }                                                                                            \
-        hipLaunchKernelGGL((k_welch_finish<NN>), dim3((NN + 255) / 256), dim3(256), 0, g.stream, partial, G, sided, \
+        hipLaunchKernelGGL((k_welch_finish<NN>), dim3((NN + SP_FIN_BINS - 1) / SP_FIN_BINS),         \
+                           dim3(SP_FIN_BINS * SP_FIN_SLICES), 0, g.stream, partial, G, sided,        \
                            scale / (double)nframes, out_d);                                          \
     }
     SP_DISPATCH_N(nfft, L_)
@@ -256,8 +257,9 @@ int dev_welch_csd(const void *x, const void *y, int dtype, int nch, int64_t y_ld
         else                                                                                         \
             hipLaunchKernelGGL((k_welch_csd<NN, false>), dim3(blocks, nch), dim3(C::WG), C::lds_bytes(1), g.stream, \
                                x, y, y_ld, win_d, hop, nframes, fpg, mean_x_d, mean_y_d, tw, partial, G); \
-        hipLaunchKernelGGL((k_csd_finish<NN>), dim3((NN + 255) / 256, nch), dim3(256), 0, g.stream, partial, G, nch, \
-                           sided, scale / (double)nframes, pxx_d, pyy_d, pxy_d);                     \
+        hipLaunchKernelGGL((k_csd_finish<NN>), dim3((NN + SP_FIN_BINS - 1) / SP_FIN_BINS, nch),      \
+                           dim3(SP_FIN_BINS * SP_FIN_SLICES), 0, g.stream, partial, G, nch, sided,   \
+                           scale / (double)nframes, pxx_d, pyy_d, pxy_d);                            \
     }
     SP_DISPATCH_N(nfft, L_)
 #undef L_
