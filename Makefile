@@ -4,7 +4,7 @@ ARCH    ?= gfx950
 CSRC    := pyfft_amd/csrc
 LIBDIR  := pyfft_amd/lib
 OBJDIR  := build/obj
-FLAGS   := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
+FLAGS   := -O3 -std=c++17 -fPIC -fno-slp-vectorize --offload-arch=$(ARCH) -Iinclude -I$(CSRC) -Wall -Wno-unused-function
 
 SRCS    := $(wildcard $(CSRC)/*.hip)
 OBJS    := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
@@ -12,7 +12,7 @@ HDRS    := $(wildcard $(CSRC)/*.h) include/spectral.h
 
 all: $(LIBDIR)/libspectral.so
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS)
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS) Makefile
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(FLAGS) -c $< -o $@
 

@@ -49,6 +49,7 @@ int sp_max_wg_fft(void);             /* largest power-of-two FFT done inside one
  * recorded on the launch stream; sp_profile_last_ms() waits for them and returns the kernel's duration. */
 int sp_profile_enable(int on);
 int sp_profile_last_ms(double *ms);
+const char *sp_profile_last_kernel(void); /* name of the kernel the last Welch call dispatched */
 /* device properties used by the host to size grids: out[0]=CU count, out[1]=LDS bytes/CU,
  * out[2]=clock kHz, out[3]=wavefront size */
 int sp_device_info(int64_t out[4]);
@@ -61,23 +62,28 @@ int sp_device_info(int64_t out[4]);
 int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int direction, int mem);
 
 /* ---- A3+A4: fftanal.fft_win -> Pstft -> averagewins (fft_analysis.py:2126-2203,
- *      :1944-1990), the fused Welch PSD: per frame g, X_g = FFT(win * (x[g*hop : g*hop+nfft] - mean));
+ *      :1944-1990), the fused Welch PSD: per frame g, X_g = FFT(win * (x[g*hop : g*hop+nfft] - trend));
  *      pxx[k] = scale/nframes * sum_g |X_g[k]|^2 with the sidedness permutation/doubling.
- *      mean_re/mean_im: value subtracted from every sample (global detrend, :2148); pass 0,0
- *      for detrend 'none'.  If `want_mean` != 0 the library computes the mean of x[0:nsig]
- *      itself (one extra pass) and ignores mean_re/im.
- *      nbins = nfft/2 for SP_SIDED_ONE (nfft even), nfft otherwise. */
+ *      nfft: any length >= 2 (non powers of two use the fused Bluestein path, up to sp_max_wg_fft()/2).
+ *      detrend (global detrend over x[0:nsig], fft_analysis.py:2148, :2539-2549):
+ *        SP_DETREND_CONST  (0) subtract the given constant mean_re + i mean_im (0,0 = no detrend),
+ *        SP_DETREND_MEAN   (1) the library computes and subtracts the mean (one extra pass over x),
+ *        SP_DETREND_LINEAR (2) the library fits and subtracts the least-squares line.
+ *      nbins = Nnyquist for SP_SIDED_ONE (nfft/2, or (nfft+1)/2 when odd), nfft otherwise. */
+#define SP_DETREND_CONST 0
+#define SP_DETREND_MEAN 1
+#define SP_DETREND_LINEAR 2
 int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop,
-                 int64_t nframes, int want_mean, double mean_re, double mean_im, int sided,
+                 int64_t nframes, int detrend, double mean_re, double mean_im, int sided,
                  double scale, double *pxx_out, int mem);
 
 /* ---- A5: fft_pwelch numeric core (fft_analysis.py:339-446): reference x against nch
  *      channels y[c][0:nsig] (channel-major, row stride y_ld samples).
  *      pxx[nbins], pyy[nch][nbins], pxy[nch][nbins] complex (re,im doubles) = Y_c * conj(X)
  *      (function-path conjugation, :393; the class path's X*conj(Y), :1960, is its conjugate).
- *      means: want_mean as above (per signal); else mean_x / mean_y[nch] are subtracted. */
+ *      detrend as above (per signal); SP_DETREND_CONST subtracts mean_x / mean_y[nch] (NULL = 0). */
 int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch, int64_t y_ld,
-                 const float *win, int nfft, int hop, int64_t nframes, int want_mean,
+                 const float *win, int nfft, int hop, int64_t nframes, int detrend,
                  const double *mean_x /*[2]*/, const double *mean_y /*[nch][2]*/, int sided,
                  double scale, double *pxx, double *pyy, double *pxy, int mem);
 
@@ -85,7 +91,7 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
  *      (generalises the ref x channel loop fft_analysis.py:387-393 / HeatPulse_Funcs.py:576-583).
  *      g_out[nfft/2+1][nch][nch] complex double, = scale/nframes * sum_g X_i conj(X_j), no doubling. */
 int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft,
-                  int hop, int64_t nframes, int want_mean, double scale, double *g_out, int mem);
+                  int hop, int64_t nframes, int detrend, double scale, double *g_out, int mem);
 
 /* ---- A8/A9: spectrogram.stft -> fftanal.fft_win (spectrogram.py:140-168, fft_analysis.py:2126-2203)
  *      and spectrogram.specgram (spectrogram.py:91-112).
@@ -95,7 +101,7 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
  *      pseg_out (may be NULL): float64[nframes] = trapz(|win*(x-mean)|^2) with unit spacing (:2174; host
  *      multiplies by dt and divides by S2). */
 int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-            int want_mean, double mean_re, double mean_im, int sided, double amp_scale, int out_kind,
+            int detrend, double mean_re, double mean_im, int sided, double amp_scale, int out_kind,
             int out_major, void *out, double *pseg_out, int mem);
 
 /* ---- A10: hilbert.hilbert / hilbert_1d (hilbert.py:22-112): rows of n_in real samples (row stride

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libspectral.so")
 
 DTYPE_F32, DTYPE_C64 = 0, 1
 SIDED_ONE, SIDED_TWO, SIDED_RAW = 1, 2, 3
+DETREND_CONST, DETREND_MEAN, DETREND_LINEAR = 0, 1, 2
 
 _lib = None
 
@@ -31,6 +32,7 @@ SIGNATURES = {
     "sp_device_info": (_i, [C.POINTER(_i64)]),
     "sp_profile_enable": (_i, [_i]),
     "sp_profile_last_ms": (_i, [C.POINTER(_d)]),
+    "sp_profile_last_kernel": (C.c_char_p, []),
     "sp_fft_c2c": (_i, [_vp, _vp, _i64, _i64, _i, _i]),
     "sp_welch_psd": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i, _d, _d, _i, _d, _vp, _i]),
     "sp_welch_csd": (_i, [_vp, _vp, _i, _i64, _i, _i64, _vp, _i, _i, _i64, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _i]),

@@ -1,0 +1,33 @@
+// k_csd.hip -- reference-vs-channels cross-spectral density launchers
+#include "launch.h"
+namespace sp {
+
+int launch_csd(LaunchCtx c, const void *x, const void *y, bool cplx, int nch, int64_t y_ld, const float *win, int hop,
+               int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,
+               const RunPart &rp) {
+#define L_(XT, CP, LN)                                                                                \
+    hipLaunchKernelGGL((k_welch_csd<XT, CP, LN>), dim3(rp.blocks, nch), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, \
+                       y, y_ld, win, hop, nframes, rp.fpg, trend_x, trend_y, xf.tb, partial, rp.groups)
+#define M_(XT)                                                                                        \
+    if (cplx) {                                                                                       \
+        if (lin) L_(XT, true, true);                                                                  \
+        else L_(XT, true, false);                                                                     \
+    } else {                                                                                          \
+        if (lin) L_(XT, false, true);                                                                 \
+        else L_(XT, false, false);                                                                    \
+    }
+    SP_DISPATCH_X(xf, M_)
+#undef M_
+#undef L_
+    return 0;
+}
+
+int launch_csd_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
+                      double *pxx, double *pyy, double *pxy) {
+    const int n = xf.tb.n;
+    hipLaunchKernelGGL(k_csd_finish, dim3((n + SP_FIN_BINS - 1) / SP_FIN_BINS, nch), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
+                       c.stream, partial, G, xf.L, n, nch, sided, scale, pxx, pyy, pxy);
+    return 0;
+}
+
+}   // namespace sp

@@ -1,0 +1,74 @@
+// k_fft.hip -- batched C2C, Hilbert, FIR, cross-covariance launchers
+#include "launch.h"
+namespace sp {
+
+int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf) {
+    const int blocks = strided_blocks(xf.L, batch, c.ncu);
+#define M_(XT)                                                                                        \
+    hipLaunchKernelGGL((k_fft_c2c<XT>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, batch, \
+                       inverse, xf.tb);
+    SP_DISPATCH_X(xf, M_)
+#undef M_
+    return 0;
+}
+
+int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out) {
+    const int blocks = strided_blocks(xf.L, batch, c.ncu);
+#define M_(XT)                                                                                        \
+    hipLaunchKernelGGL((k_hilbert<XT>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n_in, x_ld, \
+                       batch, xf.tb, out);
+    SP_DISPATCH_X(xf, M_)
+#undef M_
+    return 0;
+}
+
+int launch_fftfilt(LaunchCtx c, const float *x, int64_t n, int ntaps, const cf *Hs, const Xf &xf, float *y) {
+    const int64_t Lb = xf.L - (ntaps - 1);
+    const int64_t npairs = ((n + Lb - 1) / Lb + 1) / 2;
+    const int blocks = strided_blocks(xf.L, npairs, c.ncu);
+#define M_(XT)                                                                                        \
+    hipLaunchKernelGGL((k_fftfilt<XT::L>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n, ntaps, \
+                       Hs, xf.tb, y);
+    SP_DISPATCH_P(xf, M_)
+#undef M_
+    return 0;
+}
+
+int launch_xcorr(LaunchCtx c, const float *x1, const float *x2, int64_t n, const double *mom, const Xf &xf, float *co) {
+#define M_(XT)                                                                                        \
+    hipLaunchKernelGGL((k_xcorr<XT::L>), dim3(1), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x1, x2, n, mom, \
+                       xf.tb, co);
+    SP_DISPATCH_P(xf, M_)
+#undef M_
+    return 0;
+}
+
+int launch_moments(LaunchCtx c, const void *x, bool cplx, int64_t n, int mode, double *partial, double *out_d,
+                   float *trend_f) {
+    int64_t nb = (n + 256 * 16 - 1) / (256 * 16);
+    if (nb > 4096) nb = 4096;
+    if (nb < 1) nb = 1;
+    const bool lin = mode == 2;
+    if (cplx) {
+        if (lin) hipLaunchKernelGGL((k_moments_partial<true, true>), dim3((int)nb), dim3(256), 0, c.stream, x, n, partial);
+        else hipLaunchKernelGGL((k_moments_partial<true, false>), dim3((int)nb), dim3(256), 0, c.stream, x, n, partial);
+    } else {
+        if (lin) hipLaunchKernelGGL((k_moments_partial<false, true>), dim3((int)nb), dim3(256), 0, c.stream, x, n, partial);
+        else hipLaunchKernelGGL((k_moments_partial<false, false>), dim3((int)nb), dim3(256), 0, c.stream, x, n, partial);
+    }
+    hipLaunchKernelGGL(k_moments_finish, dim3(1), dim3(256), 0, c.stream, partial, (int)nb, n, mode, out_d, trend_f);
+    return 0;
+}
+
+int launch_transpose(LaunchCtx c, const void *in, void *out, int64_t rows, int64_t cols, int elem_bytes) {
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    if (elem_bytes == 4)
+        hipLaunchKernelGGL((k_transpose<float>), grid, dim3(32, 8), 0, c.stream, (const float *)in, (float *)out, rows, cols);
+    else if (elem_bytes == 8)
+        hipLaunchKernelGGL((k_transpose<cf>), grid, dim3(32, 8), 0, c.stream, (const cf *)in, (cf *)out, rows, cols);
+    else
+        return -1;
+    return 0;
+}
+
+}   // namespace sp

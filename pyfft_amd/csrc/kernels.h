@@ -1,17 +1,25 @@
 // kernels.h -- gfx950 kernels of the spectral hot path, all built on WgFft (fft_core.h).
 //
 // Layout in HBM: signals are contiguous sample vectors (float32 or interleaved complex64);
-// frames are never materialised -- frame g is the window [g*hop, g*hop+N) of the signal.
-// A workgroup hosts FPW = 256/T transform groups (T = N/16 threads each); a group owns a run
+// frames are never materialised -- frame g is the window [g*hop, g*hop+n) of the signal.
+// A workgroup hosts FPW = 256/T transform groups (T = L/16 threads each); a group owns a run
 // of consecutive frames (Welch/STFT) or a strided set of rows/blocks (FFT/Hilbert/FIR).
+//
+// Every kernel is templated on a transform policy X:
+//   XfPow2<N>  : n == N, one workgroup Stockham FFT (the fast path, BASELINE sizes);
+//   XfBlue<L>  : any n with 2n-1 <= L: Bluestein chirp-z  X[k] = c*[k] IFFT_L(FFT_L(x c*) . FFT_L(c))[k]
+//                with c[m] = exp(i pi m^2/n); both L-point transforms run in the same workgroup,
+//                so non-power-of-two segment lengths (the reference's usual case: nwins =
+//                floor(nsig/(Navr(1-ov)+ov))) stay one fused kernel.
+// Register contract of X::fwd: v[t] <-> element tid + T*t (t < 16), valid for indices < n.
 #pragma once
 #include "fft_core.h"
 #include <stdint.h>
 
 namespace sp {
 
-template <int N> struct WgCfg {
-    using PL = FftPlan<N>;
+template <int L> struct WgCfg {
+    using PL = FftPlan<L>;
     static constexpr int R = PL::R, T = PL::T;
     static constexpr int WG = T >= 256 ? T : 256;
     static constexpr int FPW = WG / T;
@@ -19,39 +27,110 @@ template <int N> struct WgCfg {
     static constexpr size_t lds_bytes(int nbuf) { return (size_t)FPW * LDS_PER * sizeof(cf) * nbuf; }
 };
 
+// device tables of one transform length
+struct XfTables {
+    const cf *tw;      // exp(-2 pi i m/L), m < L
+    const cf *chirp;   // Bluestein: exp(-i pi m^2/n), m < n          (null for pow2)
+    const cf *bf;      // Bluestein: FFT_L(wrapped exp(+i pi m^2/n)) / L (null for pow2)
+    int n;             // transform length
+};
+
+template <int N> struct XfPow2 {
+    static constexpr int L = N;
+    static constexpr bool EXACT = true;      // n == L at compile time
+    using C = WgCfg<N>;
+    WgFft<N, false> f;
+    __device__ __forceinline__ void init(const XfTables &tb, int tid) { f.load_twiddles(tb.tw, tid); }
+    __device__ __forceinline__ void fwd(cf (&v)[C::R], cf *lds, int tid, int) const { f.template run<true>(v, lds, lds, tid); }
+};
+
+template <int L_> struct XfBlue {
+    static constexpr int L = L_;
+    static constexpr bool EXACT = false;
+    using C = WgCfg<L_>;
+    WgFft<L_, false> f;
+    const cf *chirp, *bf;
+    __device__ __forceinline__ void init(const XfTables &tb, int tid) {
+        f.load_twiddles(tb.tw, tid);
+        chirp = tb.chirp;
+        bf = tb.bf;
+    }
+    __device__ __forceinline__ void fwd(cf (&v)[C::R], cf *lds, int tid, int n) const {
+        cf c[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int i = tid + C::T * t;
+            c[t] = chirp[i < n ? i : 0];
+            v[t] = i < n ? cmul(v[t], c[t]) : mk(0.f, 0.f);
+        }
+        f.template run<true>(v, lds, lds, tid);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = cconj(cmul(v[t], bf[tid + C::T * t]));     // conj: inverse via forward
+        f.template run<true>(v, lds, lds, tid);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = cmul(cconj(v[t]), c[t]);
+    }
+};
+
 enum { SIDED_ONE = 1, SIDED_TWO = 2, SIDED_RAW = 3 };
 
-// bin k of an N-point spectrum -> output slot and amplitude/power weights for a sidedness
-// (fft_analysis.py:2179-2193 / :402-428).  returns -1 when the bin is dropped.
-template <int N> __device__ __forceinline__ int bin_slot(int k, int sided) {
-    if (sided == SIDED_ONE) return k < N / 2 ? k : -1;
-    if (sided == SIDED_TWO) return (k + N / 2) & (N - 1);
+// bin k of an n-point spectrum -> output slot for a sidedness (fft_analysis.py:2179-2193 / :402-428);
+// -1 when the bin is dropped.  nny = n/2 (even) or (n+1)/2 (odd)  (fft_analysis.py:2471-2484)
+__device__ __forceinline__ int nyq_of(int n) { return (n & 1) ? (n + 1) / 2 : n / 2; }
+__device__ __forceinline__ int bin_slot(int k, int n, int sided) {
+    if (sided == SIDED_ONE) return k < nyq_of(n) ? k : -1;
+    if (sided == SIDED_TWO) {
+        const int s = k + n / 2;
+        return s >= n ? s - n : s;
+    }
     return k;
 }
-template <int N> __device__ __forceinline__ bool bin_doubled(int k, int sided) {
-    return sided == SIDED_ONE && k >= 1 && k <= N / 2 - 2;      // [1:-1] of the cropped array (Q1)
+// [1:-1] of the cropped array is doubled, plus the last bin when n is odd (Q1; :414-420, :2186-2188)
+__device__ __forceinline__ bool bin_doubled(int k, int n, int sided) {
+    const int nny = nyq_of(n);
+    return sided == SIDED_ONE && k >= 1 && (k <= nny - 2 || ((n & 1) && k == nny - 1));
 }
+__device__ __forceinline__ int nbins_of(int n, int sided) { return sided == SIDED_ONE ? nyq_of(n) : n; }
 
 __device__ __forceinline__ cf load_sample(const void *x, int64_t i, bool cplx) {
     if (cplx) return reinterpret_cast<const cf *>(x)[i];
     return mk(reinterpret_cast<const float *>(x)[i], 0.f);
 }
 
+// detrend parameters of one signal: value removed at global sample index i is  m + s*i
+struct Trend {
+    cf m, s;
+};
+__device__ __forceinline__ Trend load_trend(const float *p) { return Trend{mk(p[0], p[1]), mk(p[2], p[3])}; }
+template <bool LIN> __device__ __forceinline__ cf detrended(cf a, const Trend &tr, int64_t i) {
+    if constexpr (LIN) {
+        const float fi = (float)i;
+        return mk(a.x - (tr.m.x + tr.s.x * fi), a.y - (tr.m.y + tr.s.y * fi));
+    } else {
+        return a - tr.m;
+    }
+}
+
+#define SP_KERNEL_PROLOGUE(X)                                                                         \
+    using C = typename X::C;                                                                          \
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                          \
+    cf *smem = reinterpret_cast<cf *>(smem_raw);                                                      \
+    const int grp = C::FPW == 1 ? 0 : (int)threadIdx.x / C::T;                                        \
+    const int tid = C::FPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % C::T;                        \
+    cf *lds = smem + grp * C::LDS_PER;                                                                \
+    const int n = X::EXACT ? X::L : tb.n;                                                             \
+    X xf;                                                                                             \
+    xf.init(tb, tid);
+
 // ------------------------------------------------------------------------------------------
-// A7  batched C2C FFT (fft_analysis.py:2096-2116).  inverse through conj(fft(conj(.)))/N.
+// A7  batched C2C FFT (fft_analysis.py:2096-2116).  inverse through conj(fft(conj(.)))/n.
 // ------------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_c2c(const cf *__restrict__ in, cf *__restrict__ out,
-                                                           int64_t batch, int inverse, const cf *__restrict__ twt) {
-    using C = WgCfg<N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *smem = reinterpret_cast<cf *>(smem_raw);
-    const int grp = threadIdx.x / C::T, tid = threadIdx.x % C::T;
-    cf *lds = smem + grp * C::LDS_PER;
-    WgFft<N, false> f;
-    f.load_twiddles(twt, tid);
+template <class X>
+__global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in, cf *__restrict__ out, int64_t batch,
+                                                       int inverse, XfTables tb) {
+    SP_KERNEL_PROLOGUE(X)
     const float sgn = inverse ? -1.f : 1.f;
-    const float scl = inverse ? 1.f / N : 1.f;
+    const float scl = inverse ? 1.f / (float)n : 1.f;
     const int64_t stride = (int64_t)gridDim.x * C::FPW;
     for (int64_t b0 = (int64_t)blockIdx.x * C::FPW; b0 < batch; b0 += stride) {
         const int64_t b = b0 + grp;
@@ -59,42 +138,42 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_c2c(const cf *__restrict__
         const int64_t bl = act ? b : batch - 1;          // clamped: loads stay unconditional
         cf v[C::R];
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) v[t] = in[bl * N + tid + C::T * t];
+        for (int t = 0; t < C::R; ++t) {
+            const int i = tid + C::T * t;
+            v[t] = in[bl * n + (X::EXACT || i < n ? i : n - 1)];
+        }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, sgn * v[t].y);
-        f.template run<true>(v, lds, lds, tid);
+        xf.fwd(v, lds, tid, n);
         if (act) {
 #pragma unroll
-            for (int t = 0; t < C::R; ++t) out[b * N + tid + C::T * t] = mk(scl * v[t].x, sgn * scl * v[t].y);
+            for (int t = 0; t < C::R; ++t) {
+                const int i = tid + C::T * t;
+                if (X::EXACT || i < n) out[b * n + i] = mk(scl * v[t].x, sgn * scl * v[t].y);
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// A3+A4  fused Welch PSD (fft_analysis.py:2156-2176 loop + :1946 |X|^2 + :1980 mean).
+// A3+A4  fused Welch PSD (fft_analysis.py:2156-2176 loop + :1946 |X|^2 + :1980 mean), generic form.
 // Each group owns frames [gid*fpg, (gid+1)*fpg); |X|^2 is accumulated in registers over the
-// run, one partial spectrum per group goes to HBM.  mean[2] (device) is subtracted before
-// the window (global detrend :2148).
+// run, one partial spectrum per group goes to HBM.  trend[4] (device) is removed before the window
+// (global detrend :2148).
 // ------------------------------------------------------------------------------------------
-template <int N, bool CPLX>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_welch(const void *__restrict__ x, const float *__restrict__ win,
-                                                         int hop, int64_t nframes, int64_t fpg,
-                                                         const float *__restrict__ mean, const cf *__restrict__ twt,
-                                                         float *__restrict__ partial) {
-    using C = WgCfg<N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *smem = reinterpret_cast<cf *>(smem_raw);
-    const int grp = threadIdx.x / C::T, tid = threadIdx.x % C::T;
-    cf *lds = smem + grp * C::LDS_PER;
-    WgFft<N, false> f;
-    f.load_twiddles(twt, tid);
+template <class X, bool CPLX, bool LIN>
+__global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, const float *__restrict__ win, int hop,
+                                                     int64_t nframes, int64_t fpg, const float *__restrict__ trend,
+                                                     XfTables tb, float *__restrict__ partial) {
+    SP_KERNEL_PROLOGUE(X)
     float w[C::R], acc[C::R];
 #pragma unroll
     for (int t = 0; t < C::R; ++t) {
-        w[t] = win[tid + C::T * t];
+        const int i = tid + C::T * t;
+        w[t] = (X::EXACT || i < n) ? win[i] : 0.f;
         acc[t] = 0.f;
     }
-    const cf mu = mk(mean[0], mean[1]);
+    const Trend tr = load_trend(trend);
     const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
     const int64_t g0 = gid * fpg;
     for (int64_t i = 0; i < fpg; ++i) {
@@ -102,97 +181,155 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch(const void *__restrict__
         // frames past the end are clamped to the last one and weighted 0: every load is unconditional
         // (a per-load predicate makes hipcc branch around each load and serialise the round trips)
         const float keep = g < nframes ? 1.f : 0.f;
-        const int64_t base = (g < nframes ? g : nframes - 1) * hop + tid;
+        const int64_t base = (g < nframes ? g : nframes - 1) * hop;
         cf v[C::R];
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) v[t] = load_sample(x, base + C::T * t, CPLX);
+        for (int t = 0; t < C::R; ++t) {
+            const int j = tid + C::T * t;
+            v[t] = load_sample(x, base + (X::EXACT || j < n ? j : n - 1), CPLX);
+        }
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) v[t] = w[t] * (v[t] - mu);
-        f.template run<true>(v, lds, lds, tid);
+        for (int t = 0; t < C::R; ++t) v[t] = w[t] * detrended<LIN>(v[t], tr, base + tid + C::T * t);
+        xf.fwd(v, lds, tid, n);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) acc[t] += keep * cnorm(v[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) partial[gid * X::L + tid + C::T * t] = acc[t];
+}
+
+// ------------------------------------------------------------------------------------------
+// The metric kernel: power-of-two n = N, hop = SHIFT*T (the hop is a whole number of register
+// slots), so a frame advances by renaming registers: the overlapped part of the next frame is
+// carried in registers and only the SHIFT new slots per thread are read from HBM -- every sample
+// is fetched once -- and those loads are issued one frame ahead of their use (software prefetch).
+// ------------------------------------------------------------------------------------------
+template <int N, bool CPLX, int SHIFT>
+__global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(const void *__restrict__ x, const float *__restrict__ win,
+                                                               int64_t nframes, int64_t fpg,
+                                                               const float *__restrict__ trend, XfTables tb,
+                                                               float *__restrict__ partial) {
+    using X = XfPow2<N>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
+    static_assert(SHIFT >= 1 && SHIFT <= C::R, "hop must be 1..R register slots");
+    constexpr int KEEP = C::R - SHIFT;
+    const int hop = SHIFT * C::T;
+    float w[C::R], acc[C::R];
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        w[t] = win[tid + C::T * t];
+        acc[t] = 0.f;
+    }
+    const cf mu = load_trend(trend).m;
+    const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
+    const int64_t g0 = gid * fpg;
+    const int64_t last = nframes - 1;
+    cf raw[C::R];
+    {
+        const int64_t base = (g0 < nframes ? g0 : last) * hop + tid;
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) raw[t] = load_sample(x, base + C::T * t, CPLX);
+    }
+    for (int64_t i = 0; i < fpg; ++i) {
+        const int64_t g = g0 + i;
+        const float keep = g < nframes ? 1.f : 0.f;
+        // prefetch the SHIFT new slots of frame g+1 (clamped at the end of the signal; unused then)
+        cf nx[SHIFT];
+        {
+            const int64_t gn = g + 1 < nframes ? g + 1 : last;
+            const int64_t base = gn * hop + tid + (int64_t)C::T * KEEP;
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) nx[s] = load_sample(x, base + C::T * s, CPLX);
+        }
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = w[t] * (raw[t] - mu);
+        xf.fwd(v, lds, tid, N);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) acc[t] += keep * cnorm(v[t]);
+        // advance one hop: rename registers
+#pragma unroll
+        for (int t = 0; t < KEEP; ++t) raw[t] = raw[t + SHIFT];
+#pragma unroll
+        for (int s = 0; s < SHIFT; ++s) raw[KEEP + s] = nx[s];
     }
 #pragma unroll
     for (int t = 0; t < C::R; ++t) partial[gid * N + tid + C::T * t] = acc[t];
 }
 
-// sum partial[G][N] over G in double, apply sidedness + scale -> out[nbins] (double).
+// sum partial[G][L] over G in double, apply sidedness + scale -> out[nbins] (double).
 // block = 64 bins x 16 slices of the group range (1024 threads); deterministic order.
 #define SP_FIN_BINS 64
 #define SP_FIN_SLICES 16
-template <int N>
-__global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_welch_finish(const float *__restrict__ partial, int64_t G,
-                                                                              int sided, double scale,
+static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_welch_finish(const float *__restrict__ partial, int64_t G,
+                                                                              int L, int n, int sided, double scale,
                                                                               double *__restrict__ out) {
     __shared__ double sh[SP_FIN_SLICES][SP_FIN_BINS];
     const int lane = threadIdx.x % SP_FIN_BINS, sl = threadIdx.x / SP_FIN_BINS;
     const int k = blockIdx.x * SP_FIN_BINS + lane;
     double s = 0.0;
-    if (k < N)
-        for (int64_t g = sl; g < G; g += SP_FIN_SLICES) s += (double)partial[g * N + k];
+    if (k < n)
+        for (int64_t g = sl; g < G; g += SP_FIN_SLICES) s += (double)partial[g * L + k];
     sh[sl][lane] = s;
     __syncthreads();
-    if (sl == 0 && k < N) {
-        const int slot = bin_slot<N>(k, sided);
+    if (sl == 0 && k < n) {
+        const int slot = bin_slot(k, n, sided);
         if (slot >= 0) {
             double tot = 0.0;
 #pragma unroll
             for (int j = 0; j < SP_FIN_SLICES; ++j) tot += sh[j][lane];
-            out[slot] = tot * scale * (bin_doubled<N>(k, sided) ? 2.0 : 1.0);
+            out[slot] = tot * scale * (bin_doubled(k, n, sided) ? 2.0 : 1.0);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // A5  fft_pwelch core (fft_analysis.py:362-393): reference x against channel y_c.
-// grid.y = channel.  partial layout per (channel, group): [4][N] = |X|^2, |Y|^2, Re, Im of Y conj(X)
+// grid.y = channel.  partial layout per (channel, group): [4][L] = |X|^2, |Y|^2, Re, Im of Y conj(X)
+// trend_x[4], trend_y[nch][4]
 // ------------------------------------------------------------------------------------------
-template <int N, bool CPLX>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd(const void *__restrict__ x, const void *__restrict__ y,
-                                                             int64_t y_ld, const float *__restrict__ win, int hop,
-                                                             int64_t nframes, int64_t fpg,
-                                                             const float *__restrict__ mean_x,
-                                                             const float *__restrict__ mean_y,
-                                                             const cf *__restrict__ twt, float *__restrict__ partial,
-                                                             int64_t groups_total) {
-    using C = WgCfg<N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *smem = reinterpret_cast<cf *>(smem_raw);
-    const int grp = threadIdx.x / C::T, tid = threadIdx.x % C::T;
-    cf *lds = smem + grp * C::LDS_PER;
+template <class X, bool CPLX, bool LIN>
+__global__ __launch_bounds__(X::C::WG) void k_welch_csd(const void *__restrict__ x, const void *__restrict__ y,
+                                                         int64_t y_ld, const float *__restrict__ win, int hop,
+                                                         int64_t nframes, int64_t fpg, const float *__restrict__ trend_x,
+                                                         const float *__restrict__ trend_y, XfTables tb,
+                                                         float *__restrict__ partial, int64_t groups_total) {
+    SP_KERNEL_PROLOGUE(X)
     const int ch = blockIdx.y;
-    WgFft<N, false> f;
-    f.load_twiddles(twt, tid);
     float w[C::R], axx[C::R], ayy[C::R];
     cf axy[C::R];
 #pragma unroll
     for (int t = 0; t < C::R; ++t) {
-        w[t] = win[tid + C::T * t];
+        const int i = tid + C::T * t;
+        w[t] = (X::EXACT || i < n) ? win[i] : 0.f;
         axx[t] = ayy[t] = 0.f;
         axy[t] = mk(0.f, 0.f);
     }
-    const cf mux = mk(mean_x[0], mean_x[1]);
-    const cf muy = mk(mean_y[2 * ch], mean_y[2 * ch + 1]);
+    const Trend trx = load_trend(trend_x), try_ = load_trend(trend_y + 4 * ch);
     const int64_t yoff = (int64_t)ch * y_ld;
     const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
     const int64_t g0 = gid * fpg;
     for (int64_t i = 0; i < fpg; ++i) {
         const int64_t g = g0 + i;
         const float keep = g < nframes ? 1.f : 0.f;
-        const int64_t base = (g < nframes ? g : nframes - 1) * hop + tid;
+        const int64_t base = (g < nframes ? g : nframes - 1) * hop;
         cf vx[C::R], vy[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
-            vx[t] = load_sample(x, base + C::T * t, CPLX);
-            vy[t] = load_sample(y, yoff + base + C::T * t, CPLX);
+            const int j = tid + C::T * t;
+            const int64_t idx = base + (X::EXACT || j < n ? j : n - 1);
+            vx[t] = load_sample(x, idx, CPLX);
+            vy[t] = load_sample(y, yoff + idx, CPLX);
         }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
-            vx[t] = w[t] * (vx[t] - mux);
-            vy[t] = w[t] * (vy[t] - muy);
+            const int64_t idx = base + tid + C::T * t;
+            vx[t] = w[t] * detrended<LIN>(vx[t], trx, idx);
+            vy[t] = w[t] * detrended<LIN>(vy[t], try_, idx);
         }
-        f.template run<true>(vx, lds, lds, tid);
-        f.template run<true>(vy, lds, lds, tid);
+        xf.fwd(vx, lds, tid, n);
+        xf.fwd(vy, lds, tid, n);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             axx[t] += keep * cnorm(vx[t]);
@@ -201,48 +338,47 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd(const void *__restri
             axy[t] = axy[t] + keep * p;
         }
     }
-    float *p = partial + ((int64_t)ch * groups_total + gid) * 4 * N;
+    float *p = partial + ((int64_t)ch * groups_total + gid) * 4 * X::L;
 #pragma unroll
     for (int t = 0; t < C::R; ++t) {
         const int k = tid + C::T * t;
         p[k] = axx[t];
-        p[N + k] = ayy[t];
-        p[2 * N + k] = axy[t].x;
-        p[3 * N + k] = axy[t].y;
+        p[X::L + k] = ayy[t];
+        p[2 * X::L + k] = axy[t].x;
+        p[3 * X::L + k] = axy[t].y;
     }
 }
 
 // out layouts: pxx[nbins] (from channel 0's copy), pyy[nch][nbins], pxy[nch][nbins][2]
-template <int N>
-__global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_finish(const float *__restrict__ partial, int64_t G,
-                                                                            int nch, int sided, double scale,
-                                                                            double *__restrict__ pxx,
+static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_finish(const float *__restrict__ partial, int64_t G,
+                                                                            int L, int n, int nch, int sided,
+                                                                            double scale, double *__restrict__ pxx,
                                                                             double *__restrict__ pyy,
                                                                             double *__restrict__ pxy) {
     __shared__ double sh[4][SP_FIN_SLICES][SP_FIN_BINS];
     const int lane = threadIdx.x % SP_FIN_BINS, sl = threadIdx.x / SP_FIN_BINS;
     const int k = blockIdx.x * SP_FIN_BINS + lane;
     const int ch = blockIdx.y;
-    const int nb = sided == SIDED_ONE ? N / 2 : N;
+    const int nb = nbins_of(n, sided);
     double s[4] = {0, 0, 0, 0};
-    const float *p = partial + (int64_t)ch * G * 4 * N;
-    if (k < N)
+    const float *p = partial + (int64_t)ch * G * 4 * L;
+    if (k < n)
         for (int64_t g = sl; g < G; g += SP_FIN_SLICES) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] += (double)p[(g * 4 + j) * N + k];
+            for (int j = 0; j < 4; ++j) s[j] += (double)p[(g * 4 + j) * L + k];
         }
 #pragma unroll
     for (int j = 0; j < 4; ++j) sh[j][sl][lane] = s[j];
     __syncthreads();
-    if (sl == 0 && k < N) {
-        const int slot = bin_slot<N>(k, sided);
+    if (sl == 0 && k < n) {
+        const int slot = bin_slot(k, n, sided);
         if (slot >= 0) {
             double tot[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int q = 0; q < SP_FIN_SLICES; ++q) tot[j] += sh[j][q][lane];
-            const double m = scale * (bin_doubled<N>(k, sided) ? 2.0 : 1.0);
+            const double m = scale * (bin_doubled(k, n, sided) ? 2.0 : 1.0);
             if (ch == 0) pxx[slot] = tot[0] * m;
             pyy[(int64_t)ch * nb + slot] = tot[1] * m;
             pxy[((int64_t)ch * nb + slot) * 2] = tot[2] * m;
@@ -254,54 +390,54 @@ __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_finish(const
 // ------------------------------------------------------------------------------------------
 // A8/A9  STFT frames (fft_analysis.py:2156-2203; spectrogram.py:91-112).
 // out frame-major [nframes][nbins]; complex (amp * X, sqrt2 on doubled bins) or power (amp*|X|^2).
-// pseg (optional): trapz of |win*(x-mean)|^2 over the frame, unit spacing (:2174).
+// pseg (optional): trapz of |win*(x-trend)|^2 over the frame, unit spacing (:2174).
 // ------------------------------------------------------------------------------------------
-template <int N, bool CPLX>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_stft(const void *__restrict__ x, const float *__restrict__ win,
-                                                        int hop, int64_t nframes, int64_t fpg,
-                                                        const float *__restrict__ mean, const cf *__restrict__ twt,
-                                                        int sided, float amp, int out_power, void *__restrict__ out,
-                                                        double *__restrict__ pseg) {
-    using C = WgCfg<N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *smem = reinterpret_cast<cf *>(smem_raw);
-    const int grp = threadIdx.x / C::T, tid = threadIdx.x % C::T;
-    cf *lds = smem + grp * C::LDS_PER;
-    WgFft<N, false> f;
-    f.load_twiddles(twt, tid);
+template <class X, bool CPLX, bool LIN>
+__global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, const float *__restrict__ win, int hop,
+                                                    int64_t nframes, int64_t fpg, const float *__restrict__ trend,
+                                                    XfTables tb, int sided, float amp, int out_power,
+                                                    void *__restrict__ out, double *__restrict__ pseg) {
+    SP_KERNEL_PROLOGUE(X)
     float w[C::R];
 #pragma unroll
-    for (int t = 0; t < C::R; ++t) w[t] = win[tid + C::T * t];
-    const cf mu = mk(mean[0], mean[1]);
-    const int nb = sided == SIDED_ONE ? N / 2 : N;
+    for (int t = 0; t < C::R; ++t) {
+        const int i = tid + C::T * t;
+        w[t] = (X::EXACT || i < n) ? win[i] : 0.f;
+    }
+    const Trend tr = load_trend(trend);
+    const int nb = nbins_of(n, sided);
     const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
     const int64_t g0 = gid * fpg;
     for (int64_t i = 0; i < fpg; ++i) {
         const int64_t g = g0 + i;
         const bool act = g < nframes;
-        const int64_t base = (act ? g : nframes - 1) * hop + tid;
+        const int64_t base = (act ? g : nframes - 1) * hop;
         cf v[C::R];
         float pw = 0.f;
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) v[t] = load_sample(x, base + C::T * t, CPLX);
+        for (int t = 0; t < C::R; ++t) {
+            const int j = tid + C::T * t;
+            v[t] = load_sample(x, base + (X::EXACT || j < n ? j : n - 1), CPLX);
+        }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
-            v[t] = w[t] * (v[t] - mu);
-            const int n = tid + C::T * t;
-            pw += ((n == 0 || n == N - 1) ? 0.5f : 1.f) * cnorm(v[t]);
+            const int j = tid + C::T * t;
+            v[t] = w[t] * detrended<LIN>(v[t], tr, base + j);
+            pw += ((j == 0 || j == n - 1) ? 0.5f : 1.f) * cnorm(v[t]);
         }
         if (pseg != nullptr && act) atomicAdd(&pseg[g], (double)pw);
-        f.template run<true>(v, lds, lds, tid);
+        xf.fwd(v, lds, tid, n);
         if (act) {
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
                 const int k = tid + C::T * t;
-                const int slot = bin_slot<N>(k, sided);
+                if (!X::EXACT && k >= n) continue;
+                const int slot = bin_slot(k, n, sided);
                 if (slot < 0) continue;
                 if (out_power) {
                     reinterpret_cast<float *>(out)[g * nb + slot] = amp * cnorm(v[t]);
                 } else {
-                    const float a = bin_doubled<N>(k, sided) ? amp * 1.41421356237309504880f : amp;
+                    const float a = bin_doubled(k, n, sided) ? amp * 1.41421356237309504880f : amp;
                     reinterpret_cast<cf *>(out)[g * nb + slot] = a * v[t];
                 }
             }
@@ -309,7 +445,7 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft(const void *__restrict__ 
     }
 }
 
-// tiled transpose [rows][cols] -> [cols][rows], elements of ESZ bytes (4 or 8) through LDS
+// tiled transpose [rows][cols] -> [cols][rows] through LDS
 template <typename E>
 __global__ void k_transpose(const E *__restrict__ in, E *__restrict__ out, int64_t rows, int64_t cols) {
     __shared__ E tile[32][33];
@@ -327,20 +463,15 @@ __global__ void k_transpose(const E *__restrict__ in, E *__restrict__ out, int64
 
 // ------------------------------------------------------------------------------------------
 // A10  analytic signal (hilbert.py:54-67): fft -> zero [nyq+1:], double [1:nyq) -> ifft, in one
-// workgroup per row (even N here; odd / long lengths go through the generic path).
+// workgroup per row.  nyq = n/2 (even) or (n+1)/2 (odd): for odd n bin `nyq` is left untouched,
+// exactly as the reference does (Q6).
 // ------------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_hilbert(const float *__restrict__ x, int64_t n_in, int64_t x_ld,
-                                                           int64_t batch, const cf *__restrict__ twt,
-                                                           cf *__restrict__ out) {
-    using C = WgCfg<N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *smem = reinterpret_cast<cf *>(smem_raw);
-    const int grp = threadIdx.x / C::T, tid = threadIdx.x % C::T;
-    cf *lds = smem + grp * C::LDS_PER;
-    WgFft<N, false> f;
-    f.load_twiddles(twt, tid);
-    constexpr int nyq = N / 2;
+template <class X>
+__global__ __launch_bounds__(X::C::WG) void k_hilbert(const float *__restrict__ x, int64_t n_in, int64_t x_ld,
+                                                       int64_t batch, XfTables tb, cf *__restrict__ out) {
+    SP_KERNEL_PROLOGUE(X)
+    const int nyq = nyq_of(n);
+    const float inv = 1.f / (float)n;
     const int64_t stride = (int64_t)gridDim.x * C::FPW;
     for (int64_t b0 = (int64_t)blockIdx.x * C::FPW; b0 < batch; b0 += stride) {
         const int64_t b = b0 + grp;
@@ -349,44 +480,43 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_hilbert(const float *__restric
         cf v[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
-            const int n = tid + C::T * t;
-            const float a = x[bl * x_ld + (n < n_in ? n : n_in - 1)];     // clamped, unconditional
-            v[t] = mk(n < n_in ? a : 0.f, 0.f);
+            const int j = tid + C::T * t;
+            const float a = x[bl * x_ld + (j < n_in ? j : n_in - 1)];     // clamped, unconditional
+            v[t] = mk(j < n_in ? a : 0.f, 0.f);
         }
-        f.template run<true>(v, lds, lds, tid);
+        xf.fwd(v, lds, tid, n);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int k = tid + C::T * t;
             const float h = (k == 0 || k == nyq) ? 1.f : (k < nyq ? 2.f : 0.f);
             v[t] = mk(h * v[t].x, -h * v[t].y);          // mask, then conj for the inverse
         }
-        f.template run<true>(v, lds, lds, tid);
+        xf.fwd(v, lds, tid, n);
         if (act) {
 #pragma unroll
-            for (int t = 0; t < C::R; ++t) out[b * N + tid + C::T * t] = mk(v[t].x * (1.f / N), -v[t].y * (1.f / N));
+            for (int t = 0; t < C::R; ++t) {
+                const int k = tid + C::T * t;
+                if (X::EXACT || k < n) out[b * n + k] = mk(v[t].x * inv, -v[t].y * inv);
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // F1  causal FIR by overlap-save; two real blocks ride in one complex transform (h real).
-// Block b yields y[b*L : (b+1)*L) from x[b*L-(P-1) : b*L+L), L = N-(P-1).
+// Block b yields y[b*Lb : (b+1)*Lb) from x[b*Lb-(P-1) : b*Lb+Lb), Lb = N-(P-1).
 // Hs[k] = FFT_N(h)[k] / N  (scale of the inverse folded in).
 // ------------------------------------------------------------------------------------------
 template <int N>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_fftfilt(const float *__restrict__ x, int64_t n, int ntaps,
-                                                           const cf *__restrict__ Hs, const cf *__restrict__ twt,
+__global__ __launch_bounds__(WgCfg<N>::WG) void k_fftfilt(const float *__restrict__ x, int64_t nsamp, int ntaps,
+                                                           const cf *__restrict__ Hs, XfTables tb,
                                                            float *__restrict__ y) {
-    using C = WgCfg<N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *smem = reinterpret_cast<cf *>(smem_raw);
-    const int grp = threadIdx.x / C::T, tid = threadIdx.x % C::T;
-    cf *lds = smem + grp * C::LDS_PER;
-    WgFft<N, false> f;
-    f.load_twiddles(twt, tid);
+    using X = XfPow2<N>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
     const int P1 = ntaps - 1;
-    const int64_t L = N - P1;
-    const int64_t nblocks = (n + L - 1) / L;
+    const int64_t Lb = N - P1;
+    const int64_t nblocks = (nsamp + Lb - 1) / Lb;
     const int64_t npairs = (nblocks + 1) / 2;
     cf H[C::R];
 #pragma unroll
@@ -395,28 +525,28 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fftfilt(const float *__restric
     for (int64_t p0 = (int64_t)blockIdx.x * C::FPW; p0 < npairs; p0 += stride) {
         const int64_t p = p0 + grp;
         const bool act = p < npairs;
-        const int64_t s0 = 2 * p * L - P1, s1 = s0 + L;      // first input sample of each block
+        const int64_t s0 = 2 * p * Lb - P1, s1 = s0 + Lb;      // first input sample of each block
         cf v[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int m = tid + C::T * t;
             const int64_t i0 = s0 + m, i1 = s1 + m;
-            const bool in0 = act && i0 >= 0 && i0 < n, in1 = act && i1 >= 0 && i1 < n;
+            const bool in0 = act && i0 >= 0 && i0 < nsamp, in1 = act && i1 >= 0 && i1 < nsamp;
             const float a = x[in0 ? i0 : 0], b = x[in1 ? i1 : 0];      // clamped, unconditional
             v[t] = mk(in0 ? a : 0.f, in1 ? b : 0.f);
         }
-        f.template run<true>(v, lds, lds, tid);
+        xf.fwd(v, lds, tid, N);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = cconj(cmul(v[t], H[t]));
-        f.template run<true>(v, lds, lds, tid);
+        xf.fwd(v, lds, tid, N);
         if (act) {
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
                 const int m = tid + C::T * t;
                 if (m >= P1) {
                     const int64_t o0 = s0 + m, o1 = s1 + m;
-                    if (o0 < n) y[o0] = v[t].x;
-                    if (o1 < n) y[o1] = -v[t].y;        // conj of the inverse trick
+                    if (o0 < nsamp) y[o0] = v[t].x;
+                    if (o1 < nsamp) y[o1] = -v[t].y;        // conj of the inverse trick
                 }
             }
         }
@@ -426,20 +556,16 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fftfilt(const float *__restric
 // ------------------------------------------------------------------------------------------
 // A11  cross-covariance at all lags for n <= N/2 (ccf.py:74-76) in one workgroup:
 // z = (x1-m1) + i (x2-m2) zero-padded to N;  A conj(B) = Im(Z[k] Z[N-k])/2 + i (|Z[k]|^2-|Z[N-k]|^2)/4
-// moments[0..3] = mean1, mean2, 1/(n*std1*std2), unused  (device)
+// mom[0..2] = mean1, mean2, 1/(n*std1*std2)  (device)
 // ------------------------------------------------------------------------------------------
 template <int N>
 __global__ __launch_bounds__(WgCfg<N>::WG) void k_xcorr(const float *__restrict__ x1, const float *__restrict__ x2,
-                                                         int64_t n, const double *__restrict__ mom,
-                                                         const cf *__restrict__ twt, float *__restrict__ co) {
-    using C = WgCfg<N>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    cf *smem = reinterpret_cast<cf *>(smem_raw);
-    const int grp = threadIdx.x / C::T, tid = threadIdx.x % C::T;
+                                                         int64_t nsamp, const double *__restrict__ mom, XfTables tb,
+                                                         float *__restrict__ co) {
+    using X = XfPow2<N>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
     // only group 0 carries data; the others transform zeros so every thread meets the same barriers
-    cf *lds = smem + grp * C::LDS_PER;
-    WgFft<N, false> f;
-    f.load_twiddles(twt, tid);
     const bool act = grp == 0;
     const float m1 = (float)mom[0], m2 = (float)mom[1];
     const float nrm = (float)mom[2];
@@ -447,11 +573,11 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_xcorr(const float *__restrict_
 #pragma unroll
     for (int t = 0; t < C::R; ++t) {
         const int i = tid + C::T * t;
-        const bool in = act && i < n;
+        const bool in = act && i < nsamp;
         const float a = x1[in ? i : 0], b = x2[in ? i : 0];
         v[t] = in ? mk(a - m1, b - m2) : mk(0.f, 0.f);
     }
-    f.template run<true>(v, lds, lds, tid);
+    xf.fwd(v, lds, tid, N);
     // mirror exchange: Z[(N-k)%N]
     __syncthreads();
 #pragma unroll
@@ -466,81 +592,101 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_xcorr(const float *__restrict_
         // R = A conj(B); feed conj(R) to the forward transform to get the inverse
         v[t] = mk(0.5f * zz.y, -0.25f * (cnorm(z) - cnorm(zm)));
     }
-    f.template run<true>(v, lds, lds, tid);
+    xf.fwd(v, lds, tid, N);
     if (act) {
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int i = tid + C::T * t;          // r[i] = v.x / N   (imag ~ 0)
             const float r = v[t].x * (nrm / N);
             // 'full' order: j = lag + (n-1);  lag >= 0 -> r[lag], lag < 0 -> r[N+lag]
-            if (i < n) co[(n - 1) + i] = r;
-            else if (i > N - n) co[i - (N - n + 1)] = r;
+            if (i < nsamp) co[(nsamp - 1) + i] = r;
+            else if (i > N - nsamp) co[i - (N - nsamp + 1)] = r;
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// reductions: sum / sum of squares in double
+// reductions in double: sums for mean / variance / least-squares line
+// partial[block][8] = sum re, sum im, sum |x|^2, sum i*re, sum i*im, 0, 0, 0   (i = sample index)
 // ------------------------------------------------------------------------------------------
-// partial[block][4] = sum re, sum im, sum re^2+im^2, 0
-template <bool CPLX>
-__global__ void k_moments_partial(const void *__restrict__ x, int64_t n, double *__restrict__ partial) {
-    double s0 = 0, s1 = 0, s2 = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#define SP_MOM 5
+template <bool CPLX, bool LIN>
+__global__ __launch_bounds__(256) void k_moments_partial(const void *__restrict__ x, int64_t n,
+                                                          double *__restrict__ partial) {
+    double s[SP_MOM] = {0, 0, 0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const cf a = load_sample(x, i, CPLX);
-        s0 += a.x;
-        s1 += a.y;
-        s2 += (double)a.x * a.x + (double)a.y * a.y;
+        s[0] += a.x;
+        s[1] += a.y;
+        s[2] += (double)a.x * a.x + (double)a.y * a.y;
+        if constexpr (LIN) {
+            const double di = (double)i;
+            s[3] += di * a.x;
+            s[4] += di * a.y;
+        }
     }
-    __shared__ double sh[3][256];
-    sh[0][threadIdx.x] = s0;
-    sh[1][threadIdx.x] = s1;
-    sh[2][threadIdx.x] = s2;
+    __shared__ double sh[SP_MOM][256];
+#pragma unroll
+    for (int j = 0; j < SP_MOM; ++j) sh[j][threadIdx.x] = s[j];
     __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
-            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
-            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
-            sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
+#pragma unroll
+            for (int j = 0; j < SP_MOM; ++j) sh[j][threadIdx.x] += sh[j][threadIdx.x + o];
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        partial[blockIdx.x * 4 + 0] = sh[0][0];
-        partial[blockIdx.x * 4 + 1] = sh[1][0];
-        partial[blockIdx.x * 4 + 2] = sh[2][0];
-    }
+    if (threadIdx.x < SP_MOM) partial[blockIdx.x * 8 + threadIdx.x] = sh[threadIdx.x][0];
 }
 
-// one block of 256: out_d[0..1] = mean (double), out_d[2] = sum|x|^2, out_f[0..1] = mean (float)
-__global__ void k_moments_finish(const double *__restrict__ partial, int nblocks, int64_t n,
-                                 double *__restrict__ out_d, float *__restrict__ out_f) {
-    __shared__ double sh[3][256];
-    double s0 = 0, s1 = 0, s2 = 0;
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
-        s0 += partial[b * 4];
-        s1 += partial[b * 4 + 1];
-        s2 += partial[b * 4 + 2];
+// one block of 256.  out_d[0..1] = mean, out_d[2] = sum|x|^2, out_d[3..4] = sum i*x.
+// trend_f[4] (optional): mode 1 -> (mean, 0 slope); mode 2 -> least-squares line m + s*i
+static __global__ __launch_bounds__(256) void k_moments_finish(const double *__restrict__ partial, int nblocks, int64_t n,
+                                                         int mode, double *__restrict__ out_d,
+                                                         float *__restrict__ trend_f) {
+    __shared__ double sh[SP_MOM][256];
+    double s[SP_MOM] = {0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += 256) {
+#pragma unroll
+        for (int j = 0; j < SP_MOM; ++j) s[j] += partial[b * 8 + j];
     }
-    sh[0][threadIdx.x] = s0;
-    sh[1][threadIdx.x] = s1;
-    sh[2][threadIdx.x] = s2;
+#pragma unroll
+    for (int j = 0; j < SP_MOM; ++j) sh[j][threadIdx.x] = s[j];
     __syncthreads();
-    for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
-            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
-            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
-            sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
+#pragma unroll
+            for (int j = 0; j < SP_MOM; ++j) sh[j][threadIdx.x] += sh[j][threadIdx.x + o];
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        out_d[0] = sh[0][0] / (double)n;
-        out_d[1] = sh[1][0] / (double)n;
-        out_d[2] = sh[2][0];
-        if (out_f) {
-            out_f[0] = (float)(sh[0][0] / (double)n);
-            out_f[1] = (float)(sh[1][0] / (double)n);
+        const double N = (double)n;
+        const double mr = sh[0][0] / N, mi = sh[1][0] / N;
+        if (out_d) {
+            out_d[0] = mr;
+            out_d[1] = mi;
+            out_d[2] = sh[2][0];
+            out_d[3] = sh[3][0];
+            out_d[4] = sh[4][0];
+        }
+        if (trend_f) {
+            if (mode == 2 && n > 1) {
+                // least squares on i = 0..n-1:  slope = (sum i x - ibar sum x) / sum (i-ibar)^2
+                const double ibar = 0.5 * (N - 1.0);
+                const double sxx = N * (N * N - 1.0) / 12.0;
+                const double sr = (sh[3][0] - ibar * sh[0][0]) / sxx, si = (sh[4][0] - ibar * sh[1][0]) / sxx;
+                trend_f[0] = (float)(mr - sr * ibar);
+                trend_f[1] = (float)(mi - si * ibar);
+                trend_f[2] = (float)sr;
+                trend_f[3] = (float)si;
+            } else {
+                trend_f[0] = (float)mr;
+                trend_f[1] = (float)mi;
+                trend_f[2] = 0.f;
+                trend_f[3] = 0.f;
+            }
         }
     }
 }

@@ -1,0 +1,99 @@
+// launch.h -- host-side launchers, one translation unit per kernel family so they compile in parallel.
+#pragma once
+#include "kernels.h"
+#include <hip/hip_runtime.h>
+
+namespace sp {
+
+struct LaunchCtx {
+    hipStream_t stream;
+    int ncu;
+};
+
+// transform selection for a length n: pow2 workgroup FFT, or Bluestein on an L-point one
+struct Xf {
+    XfTables tb;
+    int L;
+    bool blue;
+};
+
+inline int fpw_of(int L) {
+    const int R = L < 16 ? L : 16, T = L / R, WG = T >= 256 ? T : 256;
+    return WG / T;
+}
+
+// frames are dealt to transform groups in contiguous runs
+struct RunPart {
+    int64_t groups, fpg;
+    int blocks;
+};
+inline RunPart run_partition(int L, int64_t nframes, int ncu, int groups_per_cu = 8) {
+    const int fpw = fpw_of(L);
+    const int64_t target = (int64_t)ncu * groups_per_cu * fpw;
+    int64_t f = (nframes + target - 1) / target;
+    if (f < 1) f = 1;
+    const int64_t G = (nframes + f - 1) / f;
+    RunPart r;
+    r.fpg = f;
+    r.blocks = (int)((G + fpw - 1) / fpw);
+    r.groups = (int64_t)r.blocks * fpw;
+    return r;
+}
+inline int strided_blocks(int L, int64_t items, int ncu) {
+    const int fpw = fpw_of(L);
+    int64_t b = (items + fpw - 1) / fpw;
+    const int64_t cap = (int64_t)ncu * 16;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// every launcher returns 0 or -1 (unsupported L); kernel launch errors surface through hipGetLastError
+int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf);
+int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
+                 bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, const char **kname);
+int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int sided, double scale, double *out);
+int launch_csd(LaunchCtx c, const void *x, const void *y, bool cplx, int nch, int64_t y_ld, const float *win, int hop,
+               int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,
+               const RunPart &rp);
+int launch_csd_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
+                      double *pxx, double *pyy, double *pxy);
+int launch_stft(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
+                bool lin, const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg);
+int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out);
+int launch_fftfilt(LaunchCtx c, const float *x, int64_t n, int ntaps, const cf *Hs, const Xf &xf, float *y);
+int launch_xcorr(LaunchCtx c, const float *x1, const float *x2, int64_t n, const double *mom, const Xf &xf, float *co);
+int launch_moments(LaunchCtx c, const void *x, bool cplx, int64_t n, int mode, double *partial_scratch, double *out_d,
+                   float *trend_f);
+int launch_transpose(LaunchCtx c, const void *in, void *out, int64_t rows, int64_t cols, int elem_bytes);
+
+// dispatch over the transform: MACRO(XTYPE) with XTYPE = XfPow2<L> or XfBlue<L>
+#define SP_CASE_P(Lv, MACRO) case Lv: { MACRO(XfPow2<Lv>) } break;
+#define SP_CASE_B(Lv, MACRO) case Lv: { MACRO(XfBlue<Lv>) } break;
+#define SP_DISPATCH_X(xf, MACRO)                                                                      \
+    if (!(xf).blue) {                                                                                 \
+        switch ((xf).L) {                                                                             \
+            SP_CASE_P(2, MACRO) SP_CASE_P(4, MACRO) SP_CASE_P(8, MACRO) SP_CASE_P(16, MACRO)          \
+            SP_CASE_P(32, MACRO) SP_CASE_P(64, MACRO) SP_CASE_P(128, MACRO) SP_CASE_P(256, MACRO)     \
+            SP_CASE_P(512, MACRO) SP_CASE_P(1024, MACRO) SP_CASE_P(2048, MACRO) SP_CASE_P(4096, MACRO) \
+            SP_CASE_P(8192, MACRO)                                                                    \
+            default: return -1;                                                                       \
+        }                                                                                             \
+    } else {                                                                                          \
+        switch ((xf).L) {                                                                             \
+            SP_CASE_B(16, MACRO) SP_CASE_B(32, MACRO) SP_CASE_B(64, MACRO) SP_CASE_B(128, MACRO)      \
+            SP_CASE_B(256, MACRO) SP_CASE_B(512, MACRO) SP_CASE_B(1024, MACRO) SP_CASE_B(2048, MACRO) \
+            SP_CASE_B(4096, MACRO) SP_CASE_B(8192, MACRO)                                             \
+            default: return -1;                                                                       \
+        }                                                                                             \
+    }
+#define SP_DISPATCH_P(xf, MACRO)                                                                      \
+    switch ((xf).L) {                                                                                 \
+        SP_CASE_P(2, MACRO) SP_CASE_P(4, MACRO) SP_CASE_P(8, MACRO) SP_CASE_P(16, MACRO)              \
+        SP_CASE_P(32, MACRO) SP_CASE_P(64, MACRO) SP_CASE_P(128, MACRO) SP_CASE_P(256, MACRO)         \
+        SP_CASE_P(512, MACRO) SP_CASE_P(1024, MACRO) SP_CASE_P(2048, MACRO) SP_CASE_P(4096, MACRO)    \
+        SP_CASE_P(8192, MACRO)                                                                        \
+        default: return -1;                                                                           \
+    }
+
+}   // namespace sp

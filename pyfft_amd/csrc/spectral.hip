@@ -1,11 +1,12 @@
-// spectral.hip -- C ABI (include/spectral.h) over the gfx950 kernels in kernels.h.
+// spectral.hip -- C ABI (include/spectral.h) over the gfx950 kernels (kernels.h via launch.h).
 #include "../../include/spectral.h"
-#include "kernels.h"
+#include "launch.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -15,12 +16,9 @@
 
 using namespace sp;
 
-#define SP_VERSION 100
+#define SP_VERSION 101
 #define SP_MAX_WG_FFT 8192
 
-// ------------------------------------------------------------------------------------------
-// context
-// ------------------------------------------------------------------------------------------
 namespace {
 
 thread_local std::string g_err;
@@ -39,6 +37,11 @@ int fail(const char *fmt, ...) {
     do {                                                                                              \
         hipError_t e_ = (expr);                                                                       \
         if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define LAUNCHCHK(expr)                                                                               \
+    do {                                                                                              \
+        if ((expr) != 0) return fail("%s: no kernel instantiated for this transform length (%s:%d)", #expr, __FILE__, __LINE__); \
+        HIPCHK(hipGetLastError());                                                                    \
     } while (0)
 
 struct Scratch {
@@ -61,21 +64,28 @@ struct Scratch {
     }
 };
 
+struct BlueTab {
+    cf *chirp, *bf;
+    int L;
+};
+
 struct Ctx {
     bool ready = false;
     int device = 0;
     int ncu = 256;
     hipStream_t stream = nullptr;
-    std::map<int64_t, cf *> twiddles;   // n -> device table exp(-2 pi i m/n), m < n
-    Scratch in0, in1, out0, work, small;   // staging (mem=0) and workspace
+    std::map<int64_t, cf *> twiddles;   // L -> exp(-2 pi i m/L)
+    std::map<int64_t, BlueTab> blue;    // n -> Bluestein tables
+    Scratch in0, in1, out0, work, small, trends;
     std::mutex mu;
-    // optional timing of the dominant kernel of the last call (HIP events on the launch stream)
-    bool profile = false;
-    bool prof_valid = false;
+    bool profile = false, prof_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const char *last_kernel = "";
 } g;
 
-struct ProfScope {   // brackets one kernel launch with events when profiling is on
+LaunchCtx lc() { return LaunchCtx{g.stream, g.ncu}; }
+
+struct ProfScope {   // brackets one kernel launch with HIP events on the launch stream when profiling is on
     bool on;
     ProfScope() : on(g.profile) {
         if (on) (void)hipEventRecord(g.ev0, g.stream);
@@ -91,6 +101,13 @@ struct ProfScope {   // brackets one kernel launch with events when profiling is
 int ensure_init() {
     if (g.ready) return 0;
     return sp_init(-1);
+}
+
+bool is_pow2(int64_t n) { return n >= 1 && (n & (n - 1)) == 0; }
+int64_t next_pow2(int64_t n) {
+    int64_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
 }
 
 int get_twiddles(int64_t n, const cf **out) {
@@ -112,206 +129,53 @@ int get_twiddles(int64_t n, const cf **out) {
     return 0;
 }
 
-bool is_pow2(int64_t n) { return n >= 1 && (n & (n - 1)) == 0; }
-
-// number of transform groups to launch for a run-partitioned kernel: enough workgroups to fill the
-// chip several times over, but at least `min_run` frames per group so the run amortises the twiddle /
-// window prologue and the partial-spectrum store.
-template <int N> void run_partition(int64_t nframes, int64_t *groups, int64_t *fpg, int *blocks) {
-    using C = WgCfg<N>;
-    const int64_t target_groups = (int64_t)g.ncu * 8 * C::FPW;
-    int64_t f = (nframes + target_groups - 1) / target_groups;
-    if (f < 1) f = 1;
-    int64_t G = (nframes + f - 1) / f;
-    int b = (int)((G + C::FPW - 1) / C::FPW);
-    *fpg = f;
-    *blocks = b;
-    *groups = (int64_t)b * C::FPW;
-}
-
-template <int N> int strided_blocks(int64_t items) {
-    using C = WgCfg<N>;
-    int64_t b = (items + C::FPW - 1) / C::FPW;
-    const int64_t cap = (int64_t)g.ncu * 16;
-    if (b > cap) b = cap;
-    if (b < 1) b = 1;
-    return (int)b;
-}
-
-#define SP_DISPATCH_N(n, MACRO)                                                                      \
-    switch (n) {                                                                                     \
-        case 2: MACRO(2); break;                                                                     \
-        case 4: MACRO(4); break;                                                                     \
-        case 8: MACRO(8); break;                                                                     \
-        case 16: MACRO(16); break;                                                                   \
-        case 32: MACRO(32); break;                                                                   \
-        case 64: MACRO(64); break;                                                                   \
-        case 128: MACRO(128); break;                                                                 \
-        case 256: MACRO(256); break;                                                                 \
-        case 512: MACRO(512); break;                                                                 \
-        case 1024: MACRO(1024); break;                                                               \
-        case 2048: MACRO(2048); break;                                                               \
-        case 4096: MACRO(4096); break;                                                               \
-        case 8192: MACRO(8192); break;                                                               \
-        default: return fail("internal: no workgroup FFT for n=%lld", (long long)(n));               \
+// transform plan for length n handled inside one workgroup
+int get_xf(int64_t n, Xf *xf) {
+    if (n < 2) return fail("transform length %lld too short", (long long)n);
+    if (is_pow2(n) && n <= SP_MAX_WG_FFT) {
+        xf->L = (int)n;
+        xf->blue = false;
+        xf->tb.n = (int)n;
+        xf->tb.chirp = xf->tb.bf = nullptr;
+        return get_twiddles(n, &xf->tb.tw);
     }
-
-// ---- device-side building blocks (all pointers device, enqueue on g.stream) --------------------
-
-int dev_fft_pow2_wg(const cf *in, cf *out, int n, int64_t batch, int inverse) {
-    const cf *tw;
-    if (get_twiddles(n, &tw)) return -1;
-#define L_(NN)                                                                                       \
-    {                                                                                                \
-        using C = WgCfg<NN>;                                                                         \
-        const int blocks = strided_blocks<NN>(batch);                                                \
-        hipLaunchKernelGGL((k_fft_c2c<NN>), dim3(blocks), dim3(C::WG), C::lds_bytes(1), g.stream, in, out, batch, \
-                           inverse, tw);                                                             \
+    int64_t L = next_pow2(2 * n - 1);
+    if (L < 16) L = 16;
+    if (L > SP_MAX_WG_FFT)
+        return fail("transform length %lld not supported yet (powers of two up to %d, other lengths up to %d)",
+                    (long long)n, SP_MAX_WG_FFT, SP_MAX_WG_FFT / 2);
+    xf->L = (int)L;
+    xf->blue = true;
+    xf->tb.n = (int)n;
+    if (get_twiddles(L, &xf->tb.tw)) return -1;
+    auto it = g.blue.find(n);
+    if (it == g.blue.end()) {
+        // chirp[m] = exp(-i pi m^2/n); bf = FFT_L(wrapped conj(chirp)) / L   (angles reduced mod 2n in integers)
+        std::vector<cf> ch((size_t)n), bw((size_t)L, make_float2(0.f, 0.f));
+        for (int64_t m = 0; m < n; ++m) {
+            const int64_t q = (m * m) % (2 * n);
+            const double a = M_PI * (double)q / (double)n;
+            ch[(size_t)m] = make_float2((float)cos(a), (float)-sin(a));
+            const cf b = make_float2((float)(cos(a) / (double)L), (float)(sin(a) / (double)L));
+            bw[(size_t)m] = b;
+            if (m > 0) bw[(size_t)(L - m)] = b;
+        }
+        BlueTab t;
+        t.L = (int)L;
+        HIPCHK(hipMalloc((void **)&t.chirp, sizeof(cf) * (size_t)n));
+        HIPCHK(hipMalloc((void **)&t.bf, sizeof(cf) * (size_t)L));
+        HIPCHK(hipMemcpy(t.chirp, ch.data(), sizeof(cf) * (size_t)n, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(t.bf, bw.data(), sizeof(cf) * (size_t)L, hipMemcpyHostToDevice));
+        Xf p2;
+        if (get_xf(L, &p2)) return -1;
+        LAUNCHCHK(launch_fft_c2c(lc(), t.bf, t.bf, 1, 0, p2));
+        HIPCHK(hipStreamSynchronize(g.stream));
+        g.blue[n] = t;
+        it = g.blue.find(n);
     }
-    SP_DISPATCH_N(n, L_)
-#undef L_
-    HIPCHK(hipGetLastError());
+    xf->tb.chirp = it->second.chirp;
+    xf->tb.bf = it->second.bf;
     return 0;
-}
-
-int dev_moments(const void *x, int dtype, int64_t n, double *out_d /*[4] dev*/, float *out_f /*[2] dev or null*/) {
-    const int threads = 256;
-    int64_t nb = (n + threads * 8 - 1) / (threads * 8);
-    if (nb > 2048) nb = 2048;
-    if (nb < 1) nb = 1;
-    if (g.small.ensure(sizeof(double) * 4 * 2048 + 256)) return -1;
-    double *partial = (double *)g.small.p;
-    if (dtype == SP_DTYPE_C64)
-        hipLaunchKernelGGL((k_moments_partial<true>), dim3((int)nb), dim3(threads), 0, g.stream, x, n, partial);
-    else
-        hipLaunchKernelGGL((k_moments_partial<false>), dim3((int)nb), dim3(threads), 0, g.stream, x, n, partial);
-    hipLaunchKernelGGL(k_moments_finish, dim3(1), dim3(256), 0, g.stream, partial, (int)nb, n, out_d, out_f);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-// small device block of parameters: [0..1] float mean x, [2..] float mean y per channel; doubles after
-struct MeanBuf {
-    float *f = nullptr;    // device
-    double *d = nullptr;   // device
-};
-
-Scratch g_means;
-
-int get_meanbuf(int nch, MeanBuf *mb) {
-    const size_t fbytes = sizeof(float) * 2 * (size_t)(nch + 1);
-    const size_t fpad = (fbytes + 15) & ~(size_t)15;
-    if (g_means.ensure(fpad + sizeof(double) * 4 * (size_t)(nch + 1))) return -1;
-    mb->f = (float *)g_means.p;
-    mb->d = (double *)((char *)g_means.p + fpad);
-    return 0;
-}
-
-int dev_welch_psd(const void *x, int dtype, const float *win_d, int nfft, int hop, int64_t nframes,
-                  const float *mean_d, int sided, double scale, double *out_d) {
-    const cf *tw;
-    if (get_twiddles(nfft, &tw)) return -1;
-#define L_(NN)                                                                                       \
-    {                                                                                                \
-        using C = WgCfg<NN>;                                                                         \
-        int64_t G, fpg;                                                                              \
-        int blocks;                                                                                  \
-        run_partition<NN>(nframes, &G, &fpg, &blocks);                                               \
-        if (g.work.ensure(sizeof(float) * (size_t)G * NN)) return -1;                                \
-        float *partial = (float *)g.work.p;                                                          \
-        {                                                                                            \
-            ProfScope ps_;                                                                           \
-            if (dtype == SP_DTYPE_C64)                                                               \
-                hipLaunchKernelGGL((k_welch<NN, true>), dim3(blocks), dim3(C::WG), C::lds_bytes(1), g.stream, x, \
-                                   win_d, hop, nframes, fpg, mean_d, tw, partial);                   \
-            else                                                                                     \
-                hipLaunchKernelGGL((k_welch<NN, false>), dim3(blocks), dim3(C::WG), C::lds_bytes(1), g.stream, x, \
-                                   win_d, hop, nframes, fpg, mean_d, tw, partial);                   \
-        }                                                                                            \
-        hipLaunchKernelGGL((k_welch_finish<NN>), dim3((NN + SP_FIN_BINS - 1) / SP_FIN_BINS),         \
-                           dim3(SP_FIN_BINS * SP_FIN_SLICES), 0, g.stream, partial, G, sided,        \
-                           scale / (double)nframes, out_d);                                          \
-    }
-    SP_DISPATCH_N(nfft, L_)
-#undef L_
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-int dev_welch_csd(const void *x, const void *y, int dtype, int nch, int64_t y_ld, const float *win_d, int nfft,
-                  int hop, int64_t nframes, const float *mean_x_d, const float *mean_y_d, int sided, double scale,
-                  double *pxx_d, double *pyy_d, double *pxy_d) {
-    const cf *tw;
-    if (get_twiddles(nfft, &tw)) return -1;
-#define L_(NN)                                                                                       \
-    {                                                                                                \
-        using C = WgCfg<NN>;                                                                         \
-        int64_t G, fpg;                                                                              \
-        int blocks;                                                                                  \
-        run_partition<NN>(nframes, &G, &fpg, &blocks);                                               \
-        if (g.work.ensure(sizeof(float) * (size_t)G * NN * 4 * (size_t)nch)) return -1;              \
-        float *partial = (float *)g.work.p;                                                          \
-        if (dtype == SP_DTYPE_C64)                                                                   \
-            hipLaunchKernelGGL((k_welch_csd<NN, true>), dim3(blocks, nch), dim3(C::WG), C::lds_bytes(1), g.stream, \
-                               x, y, y_ld, win_d, hop, nframes, fpg, mean_x_d, mean_y_d, tw, partial, G); \
-        else                                                                                         \
-            hipLaunchKernelGGL((k_welch_csd<NN, false>), dim3(blocks, nch), dim3(C::WG), C::lds_bytes(1), g.stream, \
-                               x, y, y_ld, win_d, hop, nframes, fpg, mean_x_d, mean_y_d, tw, partial, G); \
-        hipLaunchKernelGGL((k_csd_finish<NN>), dim3((NN + SP_FIN_BINS - 1) / SP_FIN_BINS, nch),      \
-                           dim3(SP_FIN_BINS * SP_FIN_SLICES), 0, g.stream, partial, G, nch, sided,   \
-                           scale / (double)nframes, pxx_d, pyy_d, pxy_d);                            \
-    }
-    SP_DISPATCH_N(nfft, L_)
-#undef L_
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-int dev_stft(const void *x, int dtype, const float *win_d, int nfft, int hop, int64_t nframes, const float *mean_d,
-             int sided, double amp, int out_kind, void *out_d, double *pseg_d) {
-    const cf *tw;
-    if (get_twiddles(nfft, &tw)) return -1;
-    if (pseg_d) HIPCHK(hipMemsetAsync(pseg_d, 0, sizeof(double) * (size_t)nframes, g.stream));
-#define L_(NN)                                                                                       \
-    {                                                                                                \
-        using C = WgCfg<NN>;                                                                         \
-        int64_t G, fpg;                                                                              \
-        int blocks;                                                                                  \
-        run_partition<NN>(nframes, &G, &fpg, &blocks);                                               \
-        if (dtype == SP_DTYPE_C64)                                                                   \
-            hipLaunchKernelGGL((k_stft<NN, true>), dim3(blocks), dim3(C::WG), C::lds_bytes(1), g.stream, x, win_d, \
-                               hop, nframes, fpg, mean_d, tw, sided, (float)amp, out_kind, out_d, pseg_d); \
-        else                                                                                         \
-            hipLaunchKernelGGL((k_stft<NN, false>), dim3(blocks), dim3(C::WG), C::lds_bytes(1), g.stream, x, win_d, \
-                               hop, nframes, fpg, mean_d, tw, sided, (float)amp, out_kind, out_d, pseg_d); \
-    }
-    SP_DISPATCH_N(nfft, L_)
-#undef L_
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-template <typename E> int dev_transpose(const E *in, E *out, int64_t rows, int64_t cols) {
-    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
-    hipLaunchKernelGGL((k_transpose<E>), grid, dim3(32, 8), 0, g.stream, in, out, rows, cols);
-    HIPCHK(hipGetLastError());
-    return 0;
-}
-
-__global__ void k_set_means(float *f, const double *src, int count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) f[i] = (float)src[i];
-}
-
-__global__ void k_xcorr_norm(double *mom /*[8]: m1 d[0..3], m2 d[4..7]*/, int64_t n, double *out /*[4]*/) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const double m1 = mom[0], m2 = mom[4];
-        const double v1 = mom[2] / (double)n - m1 * m1, v2 = mom[6] / (double)n - m2 * m2;
-        out[0] = m1;
-        out[1] = m2;
-        out[2] = 1.0 / ((double)n * sqrt(v1 > 0 ? v1 : 0) * sqrt(v2 > 0 ? v2 : 0));
-        out[3] = 0;
-    }
 }
 
 // Small host tables (windows, filter spectra) live in a content-keyed device cache: a table is uploaded
@@ -337,7 +201,6 @@ void tables_release() {
     g_tables.clear();
 }
 
-// returns the cached device copy of `host` (bytes long); *fresh = true when it was just created
 int get_table(uint64_t kind, const void *host, size_t bytes, void **dev, bool *fresh) {
     const uint64_t key = fnv1a(host, bytes, 1469598103934665603ull ^ (kind * 0x9E3779B97F4A7C15ull) ^ bytes);
     auto it = g_tables.find(key);
@@ -359,17 +222,69 @@ int get_table(uint64_t kind, const void *host, size_t bytes, void **dev, bool *f
     return 0;
 }
 
-__global__ void k_set2(float *dst, float a, float b) {
+__global__ void k_set4(float *dst, float a, float b, float c, float d) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         dst[0] = a;
         dst[1] = b;
+        dst[2] = c;
+        dst[3] = d;
     }
 }
 
-int next_pow2(int64_t n) {
-    int64_t p = 1;
-    while (p < n) p <<= 1;
-    return (int)p;
+__global__ void k_xcorr_norm(const double *mom1, const double *mom2, int64_t n, double *out /*[4]*/) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double m1 = mom1[0], m2 = mom2[0];
+        const double v1 = mom1[2] / (double)n - m1 * m1, v2 = mom2[2] / (double)n - m2 * m2;
+        out[0] = m1;
+        out[1] = m2;
+        out[2] = 1.0 / ((double)n * sqrt(v1 > 0 ? v1 : 0) * sqrt(v2 > 0 ? v2 : 0));
+        out[3] = 0;
+    }
+}
+
+// device block: nsig trend records (4 floats each) followed by 8 doubles per signal
+struct TrendBuf {
+    float *f;
+    double *d;
+};
+int get_trendbuf(int nsig, TrendBuf *tb) {
+    const size_t fbytes = ((sizeof(float) * 4 * (size_t)nsig) + 63) & ~(size_t)63;
+    if (g.trends.ensure(fbytes + sizeof(double) * 8 * (size_t)nsig + 64)) return -1;
+    tb->f = (float *)g.trends.p;
+    tb->d = (double *)((char *)g.trends.p + fbytes);
+    return 0;
+}
+double *moments_scratch() {
+    if (g.small.ensure(sizeof(double) * 8 * 4096 + 256)) return nullptr;
+    return (double *)g.small.p;
+}
+
+// fill trend record `idx` for signal x: detrend 0 -> explicit (re,im), 1 -> mean, 2 -> LS line
+int set_trend(const TrendBuf &tb, int idx, const void *x, bool cplx, int64_t n, int detrend, double re, double im) {
+    if (detrend == 0) {
+        hipLaunchKernelGGL(k_set4, dim3(1), dim3(64), 0, g.stream, tb.f + 4 * idx, (float)re, (float)im, 0.f, 0.f);
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
+    double *scr = moments_scratch();
+    if (!scr) return -1;
+    LAUNCHCHK(launch_moments(lc(), x, cplx, n, detrend, scr, tb.d + 8 * idx, tb.f + 4 * idx));
+    return 0;
+}
+
+int check_frames(const char *who, int64_t nsig, int nfft, int hop, int64_t nframes) {
+    if (nfft < 2 || hop < 1 || nframes < 1) return fail("%s: bad nfft/hop/nframes", who);
+    if ((nframes - 1) * (int64_t)hop + nfft > nsig)
+        return fail("%s: %lld frames of %d with hop %d need %lld samples, signal has %lld", who, (long long)nframes, nfft,
+                    hop, (long long)((nframes - 1) * (int64_t)hop + nfft), (long long)nsig);
+    return 0;
+}
+
+int nbins_host(int n, int sided) { return sided == SP_SIDED_ONE ? ((n & 1) ? (n + 1) / 2 : n / 2) : n; }
+
+bool env_flag(const char *name) {
+    const char *v = getenv(name);
+    return v && v[0] && v[0] != '0';
 }
 
 }   // namespace
@@ -386,6 +301,8 @@ const char *sp_last_error(void) { return g_err.c_str(); }
 int sp_init(int device_id) {
     std::lock_guard<std::mutex> lk(g.mu);
     if (g.ready && (device_id < 0 || device_id == g.device)) return 0;
+    if (g.ready)
+        return fail("libspectral is bound to device %d for the life of the process (asked for %d)", g.device, device_id);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
         return fail("no HIP device visible (libspectral has no CPU fallback)");
@@ -410,12 +327,17 @@ void sp_shutdown(void) {
     (void)hipDeviceSynchronize();
     for (auto &kv : g.twiddles) (void)hipFree(kv.second);
     g.twiddles.clear();
+    for (auto &kv : g.blue) {
+        (void)hipFree(kv.second.chirp);
+        (void)hipFree(kv.second.bf);
+    }
+    g.blue.clear();
     g.in0.release();
     g.in1.release();
     g.out0.release();
     g.work.release();
     g.small.release();
-    g_means.release();
+    g.trends.release();
     tables_release();
     g.ready = false;
 }
@@ -453,6 +375,8 @@ int sp_profile_last_ms(double *ms) {
     return 0;
 }
 
+const char *sp_profile_last_kernel(void) { return g.last_kernel; }
+
 int sp_device_info(int64_t out[4]) {
     if (ensure_init()) return -1;
     hipDeviceProp_t prop;
@@ -475,11 +399,11 @@ int sp_mean(const void *x, int x_dtype, int64_t n, double out[2], int mem) {
         HIPCHK(hipMemcpyAsync(g.in0.p, x, esz * (size_t)n, hipMemcpyHostToDevice, g.stream));
         xd = g.in0.p;
     }
-    MeanBuf mb;
-    if (get_meanbuf(1, &mb)) return -1;
-    if (dev_moments(xd, x_dtype, n, mb.d, nullptr)) return -1;
-    double h[4];
-    HIPCHK(hipMemcpyAsync(h, mb.d, sizeof h, hipMemcpyDeviceToHost, g.stream));
+    TrendBuf tb;
+    if (get_trendbuf(1, &tb)) return -1;
+    if (set_trend(tb, 0, xd, x_dtype == SP_DTYPE_C64, n, 1, 0, 0)) return -1;
+    double h[2];
+    HIPCHK(hipMemcpyAsync(h, tb.d, sizeof h, hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     out[0] = h[0];
     out[1] = h[1];
@@ -492,16 +416,15 @@ int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int directio
     if (direction != -1 && direction != 1) return fail("sp_fft_c2c: direction must be -1 or +1");
     if (batch == 0) return 0;
     std::lock_guard<std::mutex> lk(g.mu);
-    if (!(is_pow2(n) && n >= 2 && n <= SP_MAX_WG_FFT)) {
-        if (n == 1) {
-            if (in != out) {
-                if (mem) HIPCHK(hipMemcpyAsync(out, in, 8 * (size_t)batch, hipMemcpyDeviceToDevice, g.stream));
-                else memcpy(out, in, 8 * (size_t)batch);
-            }
-            return 0;
+    if (n == 1) {
+        if (in != out) {
+            if (mem) HIPCHK(hipMemcpyAsync(out, in, 8 * (size_t)batch, hipMemcpyDeviceToDevice, g.stream));
+            else memcpy(out, in, 8 * (size_t)batch);
         }
-        return fail("sp_fft_c2c: n=%lld not supported yet (powers of two up to %d)", (long long)n, SP_MAX_WG_FFT);
+        return 0;
     }
+    Xf xf;
+    if (get_xf(n, &xf)) return -1;
     const size_t bytes = sizeof(cf) * (size_t)n * (size_t)batch;
     const cf *din = (const cf *)in;
     cf *dout = (cf *)out;
@@ -511,7 +434,7 @@ int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int directio
         din = (const cf *)g.in0.p;
         dout = (cf *)g.in0.p;
     }
-    if (dev_fft_pow2_wg(din, dout, (int)n, batch, direction > 0)) return -1;
+    LAUNCHCHK(launch_fft_c2c(lc(), din, dout, batch, direction > 0, xf));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -519,23 +442,17 @@ int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int directio
     return 0;
 }
 
-static int check_frames(const char *who, int64_t nsig, int nfft, int hop, int64_t nframes) {
-    if (nfft < 2 || hop < 1 || nframes < 1) return fail("%s: bad nfft/hop/nframes", who);
-    if ((nframes - 1) * (int64_t)hop + nfft > nsig)
-        return fail("%s: %lld frames of %d with hop %d need %lld samples, signal has %lld", who, (long long)nframes, nfft,
-                    hop, (long long)((nframes - 1) * (int64_t)hop + nfft), (long long)nsig);
-    if (!(is_pow2(nfft) && nfft <= SP_MAX_WG_FFT))
-        return fail("%s: nfft=%d not supported yet (powers of two up to %d)", who, nfft, SP_MAX_WG_FFT);
-    return 0;
-}
-
 int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-                 int want_mean, double mean_re, double mean_im, int sided, double scale, double *pxx_out, int mem) {
+                 int detrend, double mean_re, double mean_im, int sided, double scale, double *pxx_out, int mem) {
     if (ensure_init()) return -1;
     if (check_frames("sp_welch_psd", nsig, nfft, hop, nframes)) return -1;
     if (sided < 1 || sided > 3) return fail("sp_welch_psd: bad sided");
+    if (detrend < 0 || detrend > 2) return fail("sp_welch_psd: detrend must be 0, 1 or 2");
     std::lock_guard<std::mutex> lk(g.mu);
-    const size_t esz = x_dtype == SP_DTYPE_C64 ? 8 : 4;
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
+    const bool cplx = x_dtype == SP_DTYPE_C64;
+    const size_t esz = cplx ? 8 : 4;
     const void *xd = x;
     if (!mem) {
         if (g.in0.ensure(esz * (size_t)nsig)) return -1;
@@ -544,20 +461,24 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
     }
     void *win_d;
     if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
-    MeanBuf mb;
-    if (get_meanbuf(1, &mb)) return -1;
-    if (want_mean) {
-        if (dev_moments(xd, x_dtype, nsig, mb.d, mb.f)) return -1;
-    } else {
-        hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, g.stream, mb.f, (float)mean_re, (float)mean_im);
-    }
-    const int nb = sided == SP_SIDED_ONE ? nfft / 2 : nfft;
+    TrendBuf tb;
+    if (get_trendbuf(1, &tb)) return -1;
+    if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
+    const int nb = nbins_host(nfft, sided);
     double *out_d = pxx_out;
     if (!mem) {
         if (g.out0.ensure(sizeof(double) * (size_t)nb)) return -1;
         out_d = (double *)g.out0.p;
     }
-    if (dev_welch_psd(xd, x_dtype, (const float *)win_d, nfft, hop, nframes, mb.f, sided, scale, out_d)) return -1;
+    const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+    if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
+    float *partial = (float *)g.work.p;
+    {
+        ProfScope ps;
+        LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, partial, rp,
+                               !env_flag("SP_WELCH_GENERIC"), &g.last_kernel));
+    }
+    LAUNCHCHK(launch_welch_finish(lc(), partial, rp.groups, xf, sided, scale / (double)nframes, out_d));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(pxx_out, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -566,14 +487,18 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
 }
 
 int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch, int64_t y_ld, const float *win,
-                 int nfft, int hop, int64_t nframes, int want_mean, const double *mean_x, const double *mean_y,
+                 int nfft, int hop, int64_t nframes, int detrend, const double *mean_x, const double *mean_y,
                  int sided, double scale, double *pxx, double *pyy, double *pxy, int mem) {
     if (ensure_init()) return -1;
     if (check_frames("sp_welch_csd", nsig, nfft, hop, nframes)) return -1;
     if (nch < 1 || y_ld < nsig) return fail("sp_welch_csd: bad nch / y_ld");
     if (sided < 1 || sided > 3) return fail("sp_welch_csd: bad sided");
+    if (detrend < 0 || detrend > 2) return fail("sp_welch_csd: detrend must be 0, 1 or 2");
     std::lock_guard<std::mutex> lk(g.mu);
-    const size_t esz = dtype == SP_DTYPE_C64 ? 8 : 4;
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
+    const bool cplx = dtype == SP_DTYPE_C64;
+    const size_t esz = cplx ? 8 : 4;
     const void *xd = x, *yd = y;
     if (!mem) {
         if (g.in0.ensure(esz * (size_t)nsig)) return -1;
@@ -585,22 +510,14 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     }
     void *win_d;
     if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
-    MeanBuf mb;
-    if (get_meanbuf(nch, &mb)) return -1;
-    if (want_mean) {
-        if (dev_moments(xd, dtype, nsig, mb.d, mb.f)) return -1;
-        for (int c = 0; c < nch; ++c)
-            if (dev_moments((const char *)yd + esz * (size_t)y_ld * (size_t)c, dtype, nsig, mb.d + 4 * (c + 1),
-                            mb.f + 2 * (c + 1)))
-                return -1;
-    } else {
-        std::vector<float> m(2 * (size_t)(nch + 1), 0.f);
-        if (mean_x) { m[0] = (float)mean_x[0]; m[1] = (float)mean_x[1]; }
-        if (mean_y) for (int c = 0; c < 2 * nch; ++c) m[2 + c] = (float)mean_y[c];
-        HIPCHK(hipStreamSynchronize(g.stream));   // mb.f may still be read by an earlier call
-        HIPCHK(hipMemcpy(mb.f, m.data(), sizeof(float) * m.size(), hipMemcpyHostToDevice));
-    }
-    const size_t nb = sided == SP_SIDED_ONE ? nfft / 2 : nfft;
+    TrendBuf tb;
+    if (get_trendbuf(nch + 1, &tb)) return -1;
+    if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_x ? mean_x[0] : 0, mean_x ? mean_x[1] : 0)) return -1;
+    for (int c = 0; c < nch; ++c)
+        if (set_trend(tb, c + 1, (const char *)yd + esz * (size_t)y_ld * (size_t)c, cplx, nsig, detrend,
+                      mean_y ? mean_y[2 * c] : 0, mean_y ? mean_y[2 * c + 1] : 0))
+            return -1;
+    const size_t nb = (size_t)nbins_host(nfft, sided);
     double *pxx_d = pxx, *pyy_d = pyy, *pxy_d = pxy;
     if (!mem) {
         if (g.out0.ensure(sizeof(double) * nb * (1 + 3 * (size_t)nch))) return -1;
@@ -608,9 +525,12 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         pyy_d = pxx_d + nb;
         pxy_d = pyy_d + nb * nch;
     }
-    if (dev_welch_csd(xd, yd, dtype, nch, y_ld, (const float *)win_d, nfft, hop, nframes, mb.f, mb.f + 2, sided,
-                      scale, pxx_d, pyy_d, pxy_d))
-        return -1;
+    const RunPart rp = run_partition(xf.L, nframes, g.ncu, nch >= 8 ? 2 : 8);
+    if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L * 4 * (size_t)nch)) return -1;
+    float *partial = (float *)g.work.p;
+    LAUNCHCHK(launch_csd(lc(), xd, yd, cplx, nch, y_ld, (const float *)win_d, hop, nframes, tb.f, tb.f + 4, detrend == 2,
+                         xf, partial, rp));
+    LAUNCHCHK(launch_csd_finish(lc(), partial, rp.groups, xf, nch, sided, scale / (double)nframes, pxx_d, pyy_d, pxy_d));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(pxx, pxx_d, sizeof(double) * nb, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipMemcpyAsync(pyy, pyy_d, sizeof(double) * nb * nch, hipMemcpyDeviceToHost, g.stream));
@@ -621,22 +541,26 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
 }
 
 int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft, int hop,
-                  int64_t nframes, int want_mean, double scale, double *g_out, int mem) {
-    (void)x; (void)nch; (void)nsig; (void)x_ld; (void)win; (void)nfft; (void)hop; (void)nframes; (void)want_mean;
+                  int64_t nframes, int detrend, double scale, double *g_out, int mem) {
+    (void)x; (void)nch; (void)nsig; (void)x_ld; (void)win; (void)nfft; (void)hop; (void)nframes; (void)detrend;
     (void)scale; (void)g_out; (void)mem;
     return fail("sp_csd_matrix: not implemented yet");
 }
 
 int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-            int want_mean, double mean_re, double mean_im, int sided, double amp_scale, int out_kind, int out_major,
+            int detrend, double mean_re, double mean_im, int sided, double amp_scale, int out_kind, int out_major,
             void *out, double *pseg_out, int mem) {
     if (ensure_init()) return -1;
     if (check_frames("sp_stft", nsig, nfft, hop, nframes)) return -1;
     if (sided < 1 || sided > 3) return fail("sp_stft: bad sided");
+    if (detrend < 0 || detrend > 2) return fail("sp_stft: detrend must be 0, 1 or 2");
     std::lock_guard<std::mutex> lk(g.mu);
-    const size_t esz = x_dtype == SP_DTYPE_C64 ? 8 : 4;
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
+    const bool cplx = x_dtype == SP_DTYPE_C64;
+    const size_t esz = cplx ? 8 : 4;
     const size_t osz = out_kind ? 4 : 8;
-    const size_t nb = sided == SP_SIDED_ONE ? nfft / 2 : nfft;
+    const size_t nb = (size_t)nbins_host(nfft, sided);
     const size_t obytes = osz * nb * (size_t)nframes;
     const void *xd = x;
     if (!mem) {
@@ -646,35 +570,26 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
     }
     void *win_d;
     if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
-    MeanBuf mb;
-    if (get_meanbuf(1, &mb)) return -1;
-    if (want_mean) {
-        if (dev_moments(xd, x_dtype, nsig, mb.d, mb.f)) return -1;
-    } else {
-        hipLaunchKernelGGL(k_set2, dim3(1), dim3(64), 0, g.stream, mb.f, (float)mean_re, (float)mean_im);
-    }
-    // frame-major result goes to `fm`; bin-major needs a transpose into `fin`
-    void *fin = out;
+    TrendBuf tb;
+    if (get_trendbuf(1, &tb)) return -1;
+    if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
+    void *fin = out;                     // final layout
     double *pseg_d = pseg_out;
     if (!mem) {
         if (g.out0.ensure(obytes + (pseg_out ? sizeof(double) * (size_t)nframes + 16 : 0))) return -1;
         fin = g.out0.p;
         if (pseg_out) pseg_d = (double *)((char *)g.out0.p + ((obytes + 15) & ~(size_t)15));
     }
-    void *fm = fin;
+    void *fm = fin;                      // frame-major result; bin-major needs a transpose into `fin`
     if (out_major == 1) {
         if (g.work.ensure(obytes)) return -1;
         fm = g.work.p;
     }
-    if (dev_stft(xd, x_dtype, (const float *)win_d, nfft, hop, nframes, mb.f, sided, amp_scale, out_kind, fm, pseg_d))
-        return -1;
-    if (out_major == 1) {
-        if (out_kind) {
-            if (dev_transpose<float>((const float *)fm, (float *)fin, nframes, (int64_t)nb)) return -1;
-        } else {
-            if (dev_transpose<cf>((const cf *)fm, (cf *)fin, nframes, (int64_t)nb)) return -1;
-        }
-    }
+    if (pseg_d) HIPCHK(hipMemsetAsync(pseg_d, 0, sizeof(double) * (size_t)nframes, g.stream));
+    const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+    LAUNCHCHK(launch_stft(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, sided,
+                          (float)amp_scale, out_kind, fm, pseg_d));
+    if (out_major == 1) LAUNCHCHK(launch_transpose(lc(), fm, fin, nframes, (int64_t)nb, (int)osz));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(out, fin, obytes, hipMemcpyDeviceToHost, g.stream));
         if (pseg_out)
@@ -686,11 +601,10 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
 
 int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t batch, void *out, int mem) {
     if (ensure_init()) return -1;
-    if (n_in < 1 || nfft < 1 || batch < 1 || x_ld < n_in) return fail("sp_hilbert: bad sizes");
-    if (!(is_pow2(nfft) && nfft >= 2 && nfft <= SP_MAX_WG_FFT))
-        return fail("sp_hilbert: nfft=%lld not supported yet (powers of two up to %d)", (long long)nfft, SP_MAX_WG_FFT);
+    if (n_in < 1 || nfft < 2 || batch < 1 || x_ld < n_in) return fail("sp_hilbert: bad sizes");
     std::lock_guard<std::mutex> lk(g.mu);
-    const int64_t nuse = n_in < nfft ? n_in : nfft;
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
     const float *xd = x;
     cf *od = (cf *)out;
     const size_t ibytes = sizeof(float) * (size_t)x_ld * (size_t)batch;
@@ -701,18 +615,8 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
         xd = (const float *)g.in0.p;
         od = (cf *)g.out0.p;
     }
-    const cf *tw;
-    if (get_twiddles(nfft, &tw)) return -1;
-#define L_(NN)                                                                                       \
-    {                                                                                                \
-        using C = WgCfg<NN>;                                                                         \
-        const int blocks = strided_blocks<NN>(batch);                                                \
-        hipLaunchKernelGGL((k_hilbert<NN>), dim3(blocks), dim3(C::WG), C::lds_bytes(1), g.stream, xd, nuse, x_ld, \
-                           batch, tw, od);                                                           \
-    }
-    SP_DISPATCH_N((int)nfft, L_)
-#undef L_
-    HIPCHK(hipGetLastError());
+    const int64_t nuse = n_in < nfft ? n_in : nfft;
+    LAUNCHCHK(launch_hilbert(lc(), xd, nuse, x_ld, batch, xf, od));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(out, od, obytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -723,7 +627,7 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
 int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem) {
     if (ensure_init()) return -1;
     if (n < 1) return fail("sp_xcorr: n must be positive");
-    const int L = next_pow2(2 * n);
+    const int64_t L = next_pow2(2 * n) < 2 ? 2 : next_pow2(2 * n);
     if (L > SP_MAX_WG_FFT) return fail("sp_xcorr: n=%lld not supported yet (n <= %d)", (long long)n, SP_MAX_WG_FFT / 2);
     std::lock_guard<std::mutex> lk(g.mu);
     const float *a = x1, *b = x2;
@@ -737,22 +641,16 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
         b = (const float *)g.in1.p;
         od = (float *)g.out0.p;
     }
-    MeanBuf mb;
-    if (get_meanbuf(3, &mb)) return -1;
-    if (dev_moments(a, SP_DTYPE_F32, n, mb.d, nullptr)) return -1;
-    if (dev_moments(b, SP_DTYPE_F32, n, mb.d + 4, nullptr)) return -1;
-    hipLaunchKernelGGL(k_xcorr_norm, dim3(1), dim3(64), 0, g.stream, mb.d, n, mb.d + 8);
-    const cf *tw;
-    if (get_twiddles(L, &tw)) return -1;
-    const int Ln = L < 2 ? 2 : L;
-#define L_(NN)                                                                                       \
-    {                                                                                                \
-        using C = WgCfg<NN>;                                                                         \
-        hipLaunchKernelGGL((k_xcorr<NN>), dim3(1), dim3(C::WG), C::lds_bytes(1), g.stream, a, b, n, mb.d + 8, tw, od); \
-    }
-    SP_DISPATCH_N(Ln, L_)
-#undef L_
-    HIPCHK(hipGetLastError());
+    TrendBuf tb;
+    if (get_trendbuf(3, &tb)) return -1;
+    double *scr = moments_scratch();
+    if (!scr) return -1;
+    LAUNCHCHK(launch_moments(lc(), a, false, n, 1, scr, tb.d, nullptr));
+    LAUNCHCHK(launch_moments(lc(), b, false, n, 1, scr, tb.d + 8, nullptr));
+    hipLaunchKernelGGL(k_xcorr_norm, dim3(1), dim3(64), 0, g.stream, tb.d, tb.d + 8, n, tb.d + 16);
+    Xf xf;
+    if (get_xf(L, &xf)) return -1;
+    LAUNCHCHK(launch_xcorr(lc(), a, b, n, tb.d + 16, xf, od));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(co_out, od, obytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -764,20 +662,23 @@ int sp_fftfilt(const float *h, int ntaps, const float *x, int64_t n, int nfft, f
     if (ensure_init()) return -1;
     if (ntaps < 1 || n < 1) return fail("sp_fftfilt: bad sizes");
     if (nfft == 0) {
-        nfft = next_pow2(8 * (int64_t)ntaps);
-        if (nfft < 1024) nfft = 1024;
-        if (nfft > SP_MAX_WG_FFT) nfft = SP_MAX_WG_FFT;
+        int64_t c = next_pow2(8 * (int64_t)ntaps);
+        if (c < 1024) c = 1024;
+        if (c > SP_MAX_WG_FFT) c = SP_MAX_WG_FFT;
+        nfft = (int)c;
     }
     if (!(is_pow2(nfft) && nfft >= 2 && nfft <= SP_MAX_WG_FFT) || nfft < 2 * (ntaps - 1) || nfft <= ntaps - 1)
         return fail("sp_fftfilt: nfft=%d must be a power of two with 2*(ntaps-1) <= nfft <= %d", nfft, SP_MAX_WG_FFT);
     std::lock_guard<std::mutex> lk(g.mu);
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
     // Hs = FFT(h zero-padded)/nfft, cached per (taps, nfft)
     std::vector<cf> hp((size_t)nfft, make_float2(0.f, 0.f));
     for (int i = 0; i < ntaps; ++i) hp[(size_t)i] = make_float2(h[i] / (float)nfft, 0.f);
     void *H_d;
     bool fresh = false;
     if (get_table(2, hp.data(), sizeof(cf) * (size_t)nfft, &H_d, &fresh)) return -1;
-    if (fresh && dev_fft_pow2_wg((const cf *)H_d, (cf *)H_d, nfft, 1, 0)) return -1;
+    if (fresh) LAUNCHCHK(launch_fft_c2c(lc(), (const cf *)H_d, (cf *)H_d, 1, 0, xf));
     const float *xd = x;
     float *yd = y;
     const size_t bytes = sizeof(float) * (size_t)n;
@@ -787,20 +688,7 @@ int sp_fftfilt(const float *h, int ntaps, const float *x, int64_t n, int nfft, f
         xd = (const float *)g.in0.p;
         yd = (float *)g.out0.p;
     }
-    const cf *tw;
-    if (get_twiddles(nfft, &tw)) return -1;
-    const int64_t L = nfft - (ntaps - 1);
-    const int64_t npairs = ((n + L - 1) / L + 1) / 2;
-#define L_(NN)                                                                                       \
-    {                                                                                                \
-        using C = WgCfg<NN>;                                                                         \
-        const int blocks = strided_blocks<NN>(npairs);                                               \
-        hipLaunchKernelGGL((k_fftfilt<NN>), dim3(blocks), dim3(C::WG), C::lds_bytes(1), g.stream, xd, n, ntaps, \
-                           (const cf *)H_d, tw, yd);                                                 \
-    }
-    SP_DISPATCH_N(nfft, L_)
-#undef L_
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK(launch_fftfilt(lc(), xd, n, ntaps, (const cf *)H_d, xf, yd));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(y, yd, bytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));

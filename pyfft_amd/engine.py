@@ -46,7 +46,22 @@ def _win32(win):
 
 
 def nbins(nfft, sided):
-    return nfft // 2 if sided == SIDED_ONE else nfft
+    """Nnyquist bins for the reference's one-sided crop (fft_analysis.py:2471-2484), else nfft."""
+    if sided == SIDED_ONE:
+        return (nfft + 1) // 2 if nfft % 2 else nfft // 2
+    return nfft
+
+
+def _detrend_args(detrend, mean_value):
+    """detrend: False/0/None none, True/1/'mean' mean, 2/'linear' least-squares line; an explicit mean_value
+    (with detrend truthy) is subtracted as a constant instead of being computed."""
+    if detrend in (None, False, 0, "none"):
+        return _ffi.DETREND_CONST, 0j
+    if detrend in (2, "linear"):
+        return _ffi.DETREND_LINEAR, 0j
+    if mean_value is not None:
+        return _ffi.DETREND_CONST, complex(mean_value)
+    return _ffi.DETREND_MEAN, 0j
 
 
 def max_wg_fft():
@@ -113,6 +128,10 @@ def profile_last_ms():
     return ms.value
 
 
+def profile_last_kernel():
+    return (lib().sp_profile_last_kernel() or b"").decode()
+
+
 # ------------------------------------------------------------------------------------------ A3+A4
 def welch_psd(x, win, hop, nframes, detrend=True, sided=SIDED_TWO, scale=1.0, mean_value=None):
     """Fused Welch PSD: scale/nframes * sum_g |FFT(win*(x_g - mean))|^2, float64 [nbins].
@@ -120,8 +139,7 @@ def welch_psd(x, win, hop, nframes, detrend=True, sided=SIDED_TWO, scale=1.0, me
     w = _win32(win)
     nfft = w.size
     nb = nbins(nfft, sided)
-    want = 1 if (detrend and mean_value is None) else 0
-    mv = complex(mean_value) if (detrend and mean_value is not None) else 0j
+    want, mv = _detrend_args(detrend, mean_value)
     if _is_torch(x):
         _bind_stream(x)
         xs = _torch_samples(x)
@@ -155,8 +173,8 @@ def welch_csd(x, y, win, hop, nframes, detrend=True, sided=SIDED_ONE, scale=1.0)
         pyy = torch.empty((nch, nb), dtype=torch.float64, device=xs.device)
         pxy = torch.empty((nch, nb), dtype=torch.complex128, device=xs.device)
         check(lib().sp_welch_csd(ptr(xs.data_ptr()), ptr(ys.data_ptr()), _tcode(xs), xs.numel(), nch, ld, ptr(w), nfft,
-                                 int(hop), int(nframes), 1 if detrend else 0, None, None, sided, float(scale),
-                                 ptr(pxx.data_ptr()), ptr(pyy.data_ptr()), ptr(pxy.data_ptr()), 1))
+                                 int(hop), int(nframes), _detrend_args(detrend, None)[0], None, None, sided,
+                                 float(scale), ptr(pxx.data_ptr()), ptr(pyy.data_ptr()), ptr(pxy.data_ptr()), 1))
         return pxx, pyy, pxy
     xs = _ffi.as_samples(x)
     ys = np.asarray(y)
@@ -172,8 +190,8 @@ def welch_csd(x, y, win, hop, nframes, detrend=True, sided=SIDED_ONE, scale=1.0)
     pxy = np.empty((nch, nb), dtype=np.complex128)
     _ffi.init()
     check(lib().sp_welch_csd(ptr(xs), ptr(ys), _ffi.dtype_code(xs.dtype), xs.size, nch, ld, ptr(w), nfft, int(hop),
-                             int(nframes), 1 if detrend else 0, None, None, sided, float(scale), ptr(pxx), ptr(pyy),
-                             ptr(pxy), 0))
+                             int(nframes), _detrend_args(detrend, None)[0], None, None, sided, float(scale), ptr(pxx),
+                             ptr(pyy), ptr(pxy), 0))
     return pxx, pyy, pxy
 
 
@@ -185,8 +203,7 @@ def stft_frames(x, win, hop, nframes, detrend=True, sided=SIDED_ONE, amp_scale=1
     w = _win32(win)
     nfft = w.size
     nb = nbins(nfft, sided)
-    want = 1 if (detrend and mean_value is None) else 0
-    mv = complex(mean_value) if (detrend and mean_value is not None) else 0j
+    want, mv = _detrend_args(detrend, mean_value)
     shape = (nb, int(nframes)) if bin_major else (int(nframes), nb)
     if _is_torch(x):
         _bind_stream(x)

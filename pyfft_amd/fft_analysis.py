@@ -1,0 +1,553 @@
+"""Drop-in for the hot path of the reference's fft_analysis.py: `fft_pwelch(...)` and the `fftanal` class.
+
+Same names, argument meaning and return layout as the reference (fft_analysis.py:36-38,790; :1695-2048); the
+numeric core -- detrend, window, overlapped FFTs, |X|^2 / Y.conj(X), segment average, and the inverse FFTs of
+the correlation epilogue -- runs on the MI355X through libspectral.so in float32/complex64.  Segment geometry,
+window tables and the O(nfft) epilogue algebra stay on the host in float64, as in the reference.
+
+Deliberately not carried over (outside the hot-path scope): plotting (`plotit` is accepted
+and ignored), the matplotlib.mlab branch (`useMLAB=True` raises), the nT-model branch (sigx shorter than sigy),
+Monte-Carlo uncertainty helpers, integratespectra/getNpeaks/fft_deriv.
+"""
+import numpy as np
+
+from . import engine as _E
+from .windows import windows
+
+
+class Struct(object):
+    """Attribute bag (stand-in for pybaseutils.Struct used by the reference, fft_analysis.py:22)."""
+
+    def __init__(self, d=None):
+        if d is not None:
+            if not isinstance(d, dict):
+                d = d.dict_from_class()
+            for k, v in d.items():
+                setattr(self, k, v)
+
+    def dict_from_class(self):
+        return dict(self.__dict__)
+
+
+class fftinfosc(Struct):
+    """Result container of fft_pwelch (reference: fft_analysis.py:796)."""
+    pass
+
+
+# ------------------------------------------------------------------------------------------
+# segment geometry and normalisation (host, exact integer/float64 arithmetic of the reference)
+# ------------------------------------------------------------------------------------------
+def _nwins(nsig, Navr, ov):                     # fft_analysis.py:2412-2418
+    n = int(np.floor(nsig * 1.0 / (Navr - Navr * ov + ov)))
+    return nsig if n >= nsig else n
+
+
+def _noverlap(nwins, ov):                       # :2421-2422
+    return int(np.ceil(ov * nwins))
+
+
+def _navr(nsig, nwins, noverlap):               # :2425-2429
+    return 1 if nwins >= nsig else (nsig - noverlap) // (nwins - noverlap)
+
+
+def _nnyquist(nfft):                            # :2471-2484
+    return (nfft + 1) // 2 if nfft % 2 else nfft // 2
+
+
+def _norms(win, Nnyquist, Fs):                  # :2487-2510 (NENBW uses Nnyquist: reference quirk Q3)
+    S1 = np.sum(win)
+    S2 = np.sum(win ** 2.0)
+    return S1, S2, Nnyquist * 1.0 * S2 / (S1 ** 2), Fs * S2 / (S1 ** 2)
+
+
+def _fs(tvec):                                  # :2376-2377
+    return (len(tvec) - 1) / (tvec[-1] - tvec[0])
+
+
+def _sided(onesided):
+    return _E.SIDED_ONE if onesided else _E.SIDED_TWO
+
+
+def _check_detrend(style):
+    """reference convention (fft_analysis.py:2539-2549): >0 mean, 0/None none, <0 linear -> device mode 1/0/2"""
+    if style is None or style == 0:
+        return 0
+    return 2 if style < 0 else 1
+
+
+def Cxy_Cxy2(Pxx, Pyy, Pxy, ibg=None):
+    """Complex and mean-squared coherence (fft_analysis.py:1662-1688)."""
+    Pxx = np.atleast_2d(np.array(Pxx, copy=True))
+    Pyy = np.array(Pyy, copy=True)
+    Pxy = np.array(Pxy, copy=True)
+    if np.size(Pxx, axis=1) != np.size(Pyy, axis=1):
+        Pxx = Pxx.T * np.ones((1, np.size(Pyy, axis=1)), dtype=Pxx.dtype)
+    Cxy2 = Pxy * np.conj(Pxy) / (np.abs(Pxx) * np.abs(Pyy))
+    Cxy = Pxy / np.sqrt(np.abs(Pxx) * np.abs(Pyy))
+    if ibg is None:
+        return Cxy, Cxy2
+    iCxy = np.imag(Cxy) / (1.0 - np.real(Cxy))
+    Cp = np.real(Cxy - np.mean(Cxy[:, ibg], axis=-1))
+    return iCxy, Cp / (1.0 - Cp)
+
+
+def _ifft_cols(P, nfft, hermitian_half):
+    """Inverse length-nfft FFT along axis 0 on the GPU.  hermitian_half: P holds bins [0, len) of a one-sided
+    spectrum and np.fft.irfft(P, n=nfft, axis=0) semantics apply (missing bins are zero, imaginary parts of the
+    DC / Nyquist bins are dropped); returns the real result.  Otherwise a plain complex ifft."""
+    P = np.asarray(P)
+    vec = P.ndim == 1
+    P2 = P[:, None] if vec else P
+    if hermitian_half:
+        nh = nfft // 2 + 1
+        H = np.zeros((nh, P2.shape[1]), dtype=np.complex128)
+        m = min(nh, P2.shape[0])
+        H[:m] = P2[:m]
+        H[0] = H[0].real
+        if nfft % 2 == 0:
+            H[-1] = H[-1].real
+        full = np.zeros((nfft, P2.shape[1]), dtype=np.complex128)
+        full[:nh] = H
+        full[nh:] = np.conj(H[1:nfft - nh + 1][::-1])
+        out = _E.ifft(full.T).T.real.astype(np.float64)
+    else:
+        out = _E.ifft(np.ascontiguousarray(P2.T)).T.astype(np.complex128)
+    return out[:, 0] if vec else out
+
+
+# ------------------------------------------------------------------------------------------
+# fft_pwelch
+# ------------------------------------------------------------------------------------------
+def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, windowfunction=None, useMLAB=None,
+               plotit=None, verbose=None, detrend_style=None, onesided=None, **kwargs):
+    """(freq, Pxy, Pxx, Pyy, Cxy, phi_xy, fftinfo) -- see the reference docstring (fft_analysis.py:39-100).
+
+    Extra keyword: segments=True also returns the per-segment arrays (fftinfo.Xfft_seg, Yfft_seg, Pxx_seg,
+    Pyy_seg, Pxy_seg, phixy_seg) the reference always materialises (:475-481); default False."""
+    calcNavr = Navr is None
+    if windowfunction is None:
+        windowfunction = "Hanning"
+    if windowoverlap is None:
+        windowoverlap = windows(windowfunction, verbose=False)
+    if useMLAB:
+        raise NotImplementedError("useMLAB=True (matplotlib.mlab.csd) is a CPU-only branch of the reference")
+    if verbose is None:
+        verbose = False
+    if detrend_style is None:
+        detrend_style = 1
+    if tbounds is None:
+        tbounds = [tvec[0], tvec[-1]]
+    tvec = np.asarray(tvec)
+    sigx = np.asarray(sigx)
+    sigy = np.asarray(sigy)
+    if onesided is None:
+        onesided = not (np.iscomplexobj(sigx) or np.iscomplexobj(sigy))
+    want_segments = bool(kwargs.pop("segments", False))
+    dflag = _check_detrend(detrend_style)
+
+    Fs = (len(tvec) - 1) / (tvec[-1] - tvec[0])                       # :136
+    i0 = int(np.floor(Fs * (tbounds[0] - tvec[0])))                  # :143-144
+    i1 = int(np.floor(1 + Fs * (tbounds[1] - tvec[0])))
+    nsig = np.size(tvec[i0:i1])
+
+    sigy = np.atleast_2d(sigy)                                        # :163-167
+    if np.shape(sigy)[1] == len(tvec):
+        sigy = sigy.T
+    nch = np.size(sigy, axis=1)
+    if np.size(sigx, axis=0) != np.size(sigy, axis=0):
+        raise NotImplementedError("sigx and sigy of different length (nT-model branch, fft_analysis.py:170-176)")
+
+    if "minFreq" in kwargs:                                           # :180-190
+        kwargs["tper"] = 2.0 / kwargs["minFreq"]
+    if "tper" in kwargs:
+        nwins = int(Fs * kwargs["tper"])
+    else:
+        if Navr is None:
+            Navr = 8
+        calcNavr = False
+        nwins = _nwins(nsig, Navr, windowoverlap)
+    noverlap = _noverlap(nwins, windowoverlap)
+
+    reflecting = False
+    if i0 == 0 and i1 == len(tvec):                                   # :197-205 end-point reflection (Q2)
+        reflecting = True
+        sigx = np.concatenate((sigx[nwins - 1:0:-1, ...], sigx, sigx[-1:-nwins:-1, ...]), axis=0)
+        sigy = np.concatenate((sigy[nwins - 1:0:-1, ...], sigy, sigy[-1:-nwins:-1, ...]), axis=0)
+        nsig = sigx.shape[0]
+    if calcNavr:
+        Navr = _navr(nsig, nwins, noverlap)
+    if nwins >= nsig:
+        Navr = 1
+        nwins = nsig
+    nfft = nwins
+    Nnyquist = _nnyquist(nfft)
+
+    win, winparams = windows(windowfunction, nwins=nwins, verbose=verbose, msgout=True)
+    info = fftinfosc()
+    info.win = win
+    info.winparams = winparams
+    info.windowoverlap = windowoverlap
+    info.ibnds = [i0, i1]
+    info.S1, info.S2, info.NENBW, info.ENBW = _norms(win, Nnyquist, Fs)
+
+    # ---- device: detrend + window + FFT + products + segment mean  (fft_analysis.py:339-446)
+    x_in = sigx[i0:i1]
+    y_in = np.ascontiguousarray(sigy[i0:i1, :].T)                    # channel-major for coalesced frame loads
+    hop = nwins - noverlap
+    scale = 1.0 / (info.S1 ** 2) / info.ENBW                          # :432-440
+    sided = _sided(onesided)
+    pxx, pyy, pxy = _E.welch_csd(x_in, y_in, win, hop, Navr, detrend=dflag, sided=sided, scale=scale)
+    freq = np.fft.fftfreq(nfft, 1.0 / Fs)
+    freq = freq[:Nnyquist] if onesided else np.fft.fftshift(freq)
+    Pxx = pxx.astype(np.complex128)                                   # reference dtype: complex128 with zero imag
+    Pyy = pyy.T.astype(np.complex128)                                 # [nfreq, nch]
+    Pxy = np.ascontiguousarray(pxy.T)
+
+    if want_segments:
+        amp = 1.0
+        Xs, _ = _E.stft_frames(x_in, win, hop, Navr, detrend=dflag, sided=_E.SIDED_RAW, amp_scale=amp)
+        Ys = np.stack([_E.stft_frames(y_in[c], win, hop, Navr, detrend=dflag, sided=_E.SIDED_RAW,
+                                      amp_scale=amp)[0] for c in range(nch)])
+        info.Xfft_seg = Xs.astype(np.complex128)
+        info.Yfft_seg = Ys.astype(np.complex128)
+
+        def cut(P):
+            if onesided:
+                P = P[..., :Nnyquist].copy()
+                P[..., 1:-1] *= 2
+                if nfft % 2:
+                    P[..., -1] *= 2
+                return P
+            return np.fft.fftshift(P, axes=-1)
+        info.Pxx_seg = cut(info.Xfft_seg * np.conj(info.Xfft_seg)) * scale
+        info.Pyy_seg = cut(info.Yfft_seg * np.conj(info.Yfft_seg)) * scale
+        info.Pxy_seg = cut(info.Yfft_seg * np.conj(info.Xfft_seg)[None]) * scale
+        info.phixy_seg = np.angle(info.Pxy_seg)
+        info.varphi_seg = np.zeros_like(info.phixy_seg)
+
+    # ---- epilogue (fft_analysis.py:489-648); length-nfft inverse FFTs run on the GPU
+    Cxy, Cxy2 = Cxy_Cxy2(Pxx, Pyy, Pxy)
+    info.varCxy = ((1.0 - Cxy * np.conjugate(Cxy)) / np.sqrt(2 * Navr)) ** 2.0
+    info.varCxy2 = 4.0 * Cxy2 * info.varCxy
+    info.varPxx = (Pxx / np.sqrt(Navr)) ** 2.0
+    info.varPyy = (Pyy / np.sqrt(Navr)) ** 2.0
+    info.varPxy = (Pxy / np.sqrt(Navr)) ** 2.0
+    info.varPhxy = (np.sqrt(1.0 - np.abs(Cxy2))) / np.sqrt(2 * Navr * np.sqrt(np.abs(Cxy2))) ** 2.0
+    phi_xy = np.arctan2(Pxy.imag, Pxy.real)
+    info.Lxx = np.sqrt(np.abs(info.ENBW * Pxx))
+    info.Lyy = np.sqrt(np.abs(info.ENBW * Pyy))
+    info.Lxy = np.sqrt(np.abs(info.ENBW * Pxy))
+    if onesided:
+        info.Lxx[1:-1] = np.sqrt(2) * info.Lxx[1:-1]
+        info.Lyy[1:-1, :] = np.sqrt(2) * info.Lyy[1:-1, :]
+        info.Lxy[1:-1, :] = np.sqrt(2) * info.Lxy[1:-1, :]
+        if nfft % 2:
+            info.Lxx[-1] = np.sqrt(2) * info.Lxx[-1]
+            info.Lyy[-1, :] = np.sqrt(2) * info.Lyy[-1, :]
+            info.Lxy[-1, :] = np.sqrt(2) * info.Lxy[-1, :]
+
+        def halve(P):
+            R = P.copy()
+            R[1:-1, ...] *= 0.5
+            if nfft % 2:
+                R[-1, ...] *= 0.5
+            return R
+        info.Rxx = _ifft_cols(halve(Pxx), nfft, True)
+        info.Ryy = _ifft_cols(halve(Pyy), nfft, True)
+        info.Rxy = _ifft_cols(halve(Pxy), nfft, True)
+        info.iCxy = _ifft_cols(Cxy.copy(), nfft, True)
+    else:
+        info.Rxx = _ifft_cols(np.fft.ifftshift(Pxx, axes=0), nfft, False)
+        info.Ryy = _ifft_cols(np.fft.ifftshift(Pyy, axes=0), nfft, False)
+        info.Rxy = _ifft_cols(np.fft.ifftshift(Pxy, axes=0), nfft, False)
+        info.iCxy = _ifft_cols(np.fft.ifftshift(Cxy, axes=0), nfft, False)
+    s = np.sqrt(nfft)
+    info.Rxx, info.Ryy, info.Rxy, info.iCxy = info.Rxx * s, info.Ryy * s, info.Rxy * s, info.iCxy * s
+    info.Ex = info.Rxx[0, ...].copy()
+    info.Ey = info.Ryy[0, ...].copy()
+    info.corrcoef = info.Rxy / np.sqrt(np.ones((nfft, 1), dtype=info.Rxy.dtype) * (info.Ex * info.Ey))
+    for k in ("Rxx", "Ryy", "Rxy", "iCxy", "corrcoef"):
+        setattr(info, k, np.fft.fftshift(getattr(info, k), axes=0))
+    info.lags = (np.asarray(range(1, nfft + 1), dtype=int) - Nnyquist) / Fs
+    info.varLxx = (info.Lxx ** 2) * (info.varPxx / np.abs(Pxx) ** 2)
+    info.varLyy = (info.Lyy ** 2) * (info.varPyy / np.abs(Pyy) ** 2)
+    info.varLxy = (info.Lxy ** 2) * (info.varPxy / np.abs(Pxy) ** 2)
+
+    if nch == 1:                                                      # :605-631
+        Pyy, Pxy, Cxy, Cxy2, phi_xy = Pyy.flatten(), Pxy.flatten(), Cxy.flatten(), Cxy2.flatten(), phi_xy.flatten()
+        for k in ("lags", "Rxx", "Ryy", "Rxy", "corrcoef", "iCxy", "Lxx", "Lyy", "Lxy", "varLxx", "varLyy", "varLxy",
+                  "varCxy", "varCxy2", "varPxx", "varPyy", "varPxy", "varPhxy"):
+            setattr(info, k, getattr(info, k).flatten())
+
+    info.nch, info.Fs, info.Navr, info.nwins, info.noverlap = nch, Fs, Navr, nwins, noverlap
+    info.overlap, info.window, info.minFreq = windowoverlap, windowfunction, 2.0 * Fs / nwins
+    info.reflecting = reflecting
+    info.freq, info.Pxx, info.Pyy, info.Pxy = freq.copy(), Pxx.copy(), Pyy.copy(), Pxy.copy()
+    info.Cxy, info.Cxy2, info.phi_xy = Cxy.copy(), Cxy2.copy(), phi_xy.copy()
+    return freq, Pxy, Pxx, Pyy, Cxy, phi_xy, info
+
+
+# ------------------------------------------------------------------------------------------
+# fftanal
+# ------------------------------------------------------------------------------------------
+class fftanal(Struct):
+    """Welch / STFT analysis object (reference: fft_analysis.py:1695-2048).
+
+    fftanal(tvec, sigx, sigy=None, tbounds=, Navr=, windowfunction=, windowoverlap=, onesided=, detrend=,
+            tper=|minFreq=, verbose=, ...).  Extra keywords: nwins= (set the segment length directly; the
+    reference's tper path truncates int(Fs*tper), quirk Q5), segments= (default True: keep Xseg/Pxx_seg...
+    like the reference; False: averaged spectra only -- the fused, memory-light path)."""
+
+    def __init__(self, tvec=None, sigx=None, sigy=None, **kwargs):
+        self.verbose = kwargs.get("verbose", True)
+        if tvec is None or sigx is None:
+            if self.verbose:
+                print("Please give at least a time-vector [s] and a signal vector [a.u.]")
+            return
+        self.init(tvec, sigx, sigy, **kwargs)
+
+    def init(self, tvec=None, sigx=None, sigy=None, **kwargs):
+        self.nosigy = sigy is None or sigx is sigy
+        self.tvec = np.asarray(tvec)
+        self.sigx = np.asarray(sigx)
+        self.sigy = None if sigy is None else np.asarray(sigy)
+        self.tbounds = kwargs.get("tbounds", [self.tvec.min(), self.tvec.max()])
+        self.useMLAB = kwargs.get("useMLAB", False)
+        self.plotit = kwargs.get("plotit", False)
+        self.verbose = kwargs.get("verbose", True)
+        self.Navr = kwargs.get("Navr", None)
+        self.window = kwargs.get("windowfunction", "Hanning")
+        if self.window is None:
+            self.window = "Hanning"
+        self.overlap = kwargs.get("windowoverlap", windows(self.window, verbose=False))
+        self.tvecy = kwargs.get("tvecy", None)
+        self.onesided = kwargs.get("onesided", None)
+        self.detrendstyle = kwargs.get("detrend", 1)
+        self.frange = kwargs.get("frange", None)
+        self.axes = kwargs.get("axes", -1)
+        self.segments = kwargs.get("segments", True)
+        if self.useMLAB:
+            raise NotImplementedError("useMLAB=True is a CPU-only branch of the reference")
+        if self.tvecy is not None:
+            raise NotImplementedError("tvecy resampling needs pybaseutils.utils.interp (absent from the reference)")
+        if self.onesided is None:
+            self.onesided = not (np.iscomplexobj(self.sigx) or (sigy is not None and np.iscomplexobj(self.sigy)))
+        self.Fs = _fs(self.tvec)
+        self.ibounds = self.__ibounds__(self.tvec, self.tbounds)
+        self.nsig = np.size(self.tvec[self.ibounds[0]:self.ibounds[1]])
+        calcNavr = False
+        if self.Navr is None:
+            calcNavr = True
+            self.Navr = 8
+        if "minFreq" in kwargs:
+            kwargs["tper"] = 2.0 / kwargs["minFreq"]
+        if "nwins" in kwargs:
+            self.nwins = int(kwargs["nwins"])
+            calcNavr = True
+        elif "tper" in kwargs:
+            self.tper = kwargs["tper"]
+            self.nwins = int(self.Fs * self.tper)                      # :1770 (Q5)
+        else:
+            calcNavr = False
+            self.nwins = _nwins(self.nsig, self.Navr, self.overlap)
+        self.noverlap = _noverlap(self.nwins, self.overlap)
+        if calcNavr:
+            self.Navr = _navr(self.nsig, self.nwins, self.noverlap)
+        self.win, self.winparams = windows(self.window, nwins=self.nwins, verbose=self.verbose, msgout=True)
+        self.nfft = self.nwins
+        self.Nnyquist = _nnyquist(self.nwins)
+        self.S1, self.S2, self.NENBW, self.ENBW = _norms(self.win, self.Nnyquist, self.Fs)
+
+    # -- reference statics kept for callers that use them
+    _getNwins = staticmethod(_nwins)
+    _getNoverlap = staticmethod(_noverlap)
+    _getNavr = staticmethod(_navr)
+    _getNnyquist = staticmethod(_nnyquist)
+    _getNorms = staticmethod(_norms)
+    __Fs__ = staticmethod(_fs)
+
+    @staticmethod
+    def _getS1(win):
+        return np.sum(win)
+
+    @staticmethod
+    def _getS2(win):
+        return np.sum(win ** 2.0)
+
+    @staticmethod
+    def _getNENBW(Nnyquist, S1, S2):
+        return Nnyquist * 1.0 * S2 / (S1 ** 2)
+
+    @staticmethod
+    def _getENBW(Fs, S1, S2):
+        return Fs * S2 / (S1 ** 2)
+
+    @staticmethod
+    def _checkCOLA(nsig, nwins, noverlap):
+        return (nsig - nwins) % (nwins - noverlap) == 0
+
+    @staticmethod
+    def __ibounds__(tvec, tbounds):
+        Fs = _fs(tvec)
+        return [int(np.floor((tbounds[0] - tvec[0]) * Fs)), int(np.floor(1 + (tbounds[1] - tvec[0]) * Fs))]
+
+    @staticmethod
+    def __trimsig__(sigt, ibounds):
+        return sigt[ibounds[0]:ibounds[1]]
+
+    @staticmethod
+    def makewindowfn(windowfunction, nwins, verbose=True):
+        return windows(windowfunction, nwins=nwins, verbose=verbose, msgout=True)
+
+    def update(self, d=None):
+        if d is not None:
+            super(fftanal, self).__init__(d)
+
+    # -- transforms (fft_analysis.py:2096-2124) on the GPU
+    def fft(self, sig, nfft=None, axes=None):
+        return _E.fft(sig, n=self.nfft if nfft is None else nfft, axis=self.axes if axes is None else axes)
+
+    def ifft(self, sig, nfft=None, axes=None):
+        return _E.ifft(sig, n=self.nfft if nfft is None else nfft, axis=self.axes if axes is None else axes)
+
+    def fftshift(self, sig, axes=None):
+        return np.fft.fftshift(sig, axes=self.axes if axes is None else axes)
+
+    def ifftshift(self, sig, axes=None):
+        return np.fft.ifftshift(sig, axes=self.axes if axes is None else axes)
+
+    # -- fft_win (fft_analysis.py:2126-2203)
+    def fft_win(self, sig, tvec=None, detrendwin=False):
+        if detrendwin:
+            raise NotImplementedError("per-window detrend (detrendwin=True)")
+        sig = np.asarray(sig)
+        if tvec is None:
+            tvec = np.linspace(0.0, 1.0, len(sig))
+        Fs = _fs(tvec)
+        nwins, Navr, hop = self.nwins, self.Navr, self.nwins - self.noverlap
+        dflag = _check_detrend(self.detrendstyle)
+        amp = 1.0 / (self.S1 * np.sqrt(self.ENBW))                     # :2197, :2202
+        Xseg, pseg = _E.stft_frames(sig, self.win, hop, Navr, detrend=dflag, sided=_sided(self.onesided),
+                                    amp_scale=amp, want_pseg=True)
+        # mean frame time (:2163) from a running sum, and the first frame's span (:2161)
+        csum = np.concatenate(([0.0], np.cumsum(np.asarray(tvec, dtype=np.float64))))
+        st = np.arange(Navr) * hop
+        tt = (csum[st + nwins] - csum[st]) / nwins
+        if nwins < len(tvec):
+            self.tper = tvec[nwins] - tvec[0]
+        freq = np.fft.fftfreq(nwins, 1.0 / Fs)
+        freq = freq[:self.Nnyquist] if self.onesided else np.fft.fftshift(freq)
+        dt = (tvec[-1] - tvec[0]) / (len(tvec) - 1)
+        return tt, freq, Xseg.astype(np.complex128), pseg * dt / self.S2
+
+    # -- Welch (fft_analysis.py:1831-1836, :1924-2018)
+    def Xstft(self):
+        sig = self.__trimsig__(self.sigx, self.ibounds)
+        t = self.__trimsig__(self.tvec, self.ibounds)
+        self.tseg, self.freq, self.Xseg, self.Xpow = self.fft_win(sig, t)
+        self.Xfft = np.mean(self.Xseg, axis=0)
+        return self.freq, self.Xseg
+
+    def Ystft(self):
+        sig = self.__trimsig__(self.sigy, self.ibounds)
+        t = self.__trimsig__(self.tvec, self.ibounds)
+        self.tseg, self.freq, self.Yseg, self.Ypow = self.fft_win(sig, t)
+        self.Yfft = np.mean(self.Yseg, axis=0)
+        return self.freq, self.Yseg
+
+    def Pstft(self):
+        amp = np.sqrt(2) if self.onesided else 1.0
+        if hasattr(self, "Xseg"):
+            self.Pxx_seg = self.Xseg * np.conj(self.Xseg)
+            self.Lxx_seg = amp * np.sqrt(np.abs(self.ENBW * self.Pxx_seg))
+        if hasattr(self, "Yseg"):
+            self.Pyy_seg = self.Yseg * np.conj(self.Yseg)
+            self.Lyy_seg = amp * np.sqrt(np.abs(self.ENBW * self.Pyy_seg))
+        if hasattr(self, "Xseg") and hasattr(self, "Yseg"):
+            self.Pxy_seg = self.Xseg * np.conj(self.Yseg)              # class-path conjugation (Q4)
+            self.Lxy_seg = amp * np.sqrt(np.abs(self.ENBW * self.Pxy_seg))
+            self.phixy_seg = np.angle(self.Pxy_seg)
+            self.Cxy_seg, self.Cxy2_seg = Cxy_Cxy2(self.Pxx_seg, self.Pyy_seg, self.Pxy_seg)
+
+    def averagewins(self):
+        """Averaged spectra straight from the fused device kernels (no [Navr, nfft] intermediates)."""
+        i0, i1 = self.ibounds
+        x = self.sigx[i0:i1]
+        hop = self.nwins - self.noverlap
+        dflag = _check_detrend(self.detrendstyle)
+        scale = 1.0 / (self.S1 ** 2) / self.ENBW
+        sided = _sided(self.onesided)
+        if self.nosigy:
+            self.Pxx = _E.welch_psd(x, self.win, hop, self.Navr, detrend=dflag, sided=sided,
+                                    scale=scale).astype(np.complex128)
+        else:
+            y = self.sigy[i0:i1]
+            pxx, pyy, pxy = _E.welch_csd(x, y, self.win, hop, self.Navr, detrend=dflag, sided=sided, scale=scale)
+            self.Pxx = pxx.astype(np.complex128)
+            self.Pyy = pyy[0].astype(np.complex128)
+            self.Pxy = np.conj(pxy[0])                                 # X conj(Y)
+        for p in ("Pxx", "Pyy", "Pxy"):
+            if hasattr(self, p):
+                setattr(self, "var" + p, (getattr(self, p) / np.sqrt(self.Navr)) ** 2.0)
+        if hasattr(self, "Pxy"):
+            self.phi_xy = np.angle(self.Pxy)
+            Cxy, Cxy2 = Cxy_Cxy2(self.Pxx, self.Pyy[None, :], self.Pxy[None, :])
+            self.Cxy, self.Cxy2 = Cxy[0], Cxy2[0]
+            self.varPhxy = (np.sqrt(1.0 - self.Cxy2) / np.sqrt(2.0 * self.Navr * self.Cxy)) ** 2.0
+            self.varCxy = ((1 - self.Cxy2) / np.sqrt(2 * self.Navr)) ** 2.0
+            self.varCxy2 = 4.0 * self.Cxy2 * self.varCxy
+
+    def pwelch(self):
+        if self.segments:
+            self.Xstft()
+            if not self.nosigy:
+                self.Ystft()
+            self.Pstft()
+        else:
+            Fs = self.Fs
+            freq = np.fft.fftfreq(self.nwins, 1.0 / Fs)
+            self.freq = freq[:self.Nnyquist] if self.onesided else np.fft.fftshift(freq)
+        self.averagewins()
+
+    def stft(self):
+        self.pwelch()
+
+    def fftpwelch(self):
+        self.freq, self.Pxy, self.Pxx, self.Pyy, self.Cxy, self.phi_xy, self.fftinfo = fft_pwelch(
+            self.tvec, self.sigx, self.sigy, self.tbounds, Navr=self.Navr, windowoverlap=self.overlap,
+            windowfunction=self.window, useMLAB=self.useMLAB, plotit=self.plotit, verbose=self.verbose,
+            detrend_style=self.detrendstyle, onesided=self.onesided)
+        self.update(self.fftinfo)
+
+    def convert2amplitudes(self):
+        for p in ("Pxx", "Pyy", "Pxy"):
+            if hasattr(self, p):
+                tmp = np.sqrt(np.abs(self.ENBW * getattr(self, p)))
+                if self.onesided:
+                    tmp[1:-1] = np.sqrt(2) * tmp[1:-1]
+                    if self.nfft % 2:
+                        tmp[-1] = np.sqrt(2) * tmp[-1]
+                setattr(self, "L" + p[1:], tmp)
+                setattr(self, "varL" + p[1:], (tmp ** 2) * (getattr(self, "var" + p) / np.abs(getattr(self, p)) ** 2))
+
+    def crosscorr(self):
+        """Correlations from the averaged spectra (fft_analysis.py:1840-1878); inverse FFTs on the GPU."""
+        nfft = self.nwins
+        for p in ("Pxx", "Pyy", "Pxy"):
+            if hasattr(self, p):
+                tmp = getattr(self, p).copy()
+                if self.onesided:
+                    tmp[..., 1:-1] *= 0.5
+                    if nfft % 2:
+                        tmp[..., -1] *= 0.5
+                    tmp = np.sqrt(nfft) * _ifft_cols(tmp, nfft, True)
+                else:
+                    tmp = np.sqrt(nfft) * _ifft_cols(np.fft.ifftshift(tmp, axes=-1), nfft, False)
+                if p == "Pxx":
+                    self.Ex = tmp[..., 0].copy()
+                if p == "Pyy":
+                    self.Ey = tmp[..., 0].copy()
+                setattr(self, "R" + p[1:], np.fft.fftshift(tmp, axes=-1))
+        if hasattr(self, "Rxy"):
+            self.corrcoef = self.Rxy.copy() / np.sqrt(self.Ex * self.Ey)
+        self.lags = (np.asarray(range(1, nfft + 1), dtype=int) - self.Nnyquist) / self.Fs

@@ -1,0 +1,209 @@
+"""GPU parity of the drop-in modules (pyfft_amd.fft_pwelch / fftanal / specgram / stft / hilbert / ccf / fftfilt)
+against the golden fixtures captured from the reference (tests/golden/make_golden.py) -- the tests read like the
+reference's own smoke functions, with assertions.  Tolerances: float32 device math vs float64 reference."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyfft_amd
+    from pyfft_amd import _ffi
+    _ffi.init()
+    return pyfft_amd
+
+
+def close_rel(a, b, rel, what=""):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = np.max(np.abs(a - b))
+    assert err <= rel * np.max(np.abs(b)), (what, err, np.max(np.abs(b)))
+
+
+PW = {
+    "pwelch_cfg1": dict(Navr=127, windowoverlap=0.5, windowfunction="Hanning", tb=-2),
+    "pwelch_reflect": dict(Navr=15, windowfunction="Hanning", tb=None),
+    "pwelch_2ch_twosided": dict(Navr=31, windowfunction="Hamming", onesided=False, detrend_style=0, tb=-2),
+    "pwelch_minfreq_linear": dict(minFreq=2.0 * 1.0e4 / 1024.0 * 1.0000001, detrend_style=-1, tb=-2),
+    "pwelch_selftest_navr8": dict(Navr=8, windowfunction="hamming", detrend_style=1, tb=-1),
+    "pwelch_selftest_minfreq": dict(minFreq=75.0, detrend_style=1, tb=-1),
+}
+
+
+@pytest.mark.parametrize("tag", sorted(PW))
+def test_fft_pwelch_golden(P, tag):
+    g = load_golden(tag)
+    kw = dict(PW[tag])
+    tb = kw.pop("tb")
+    t, x, y = g["t"], g["x"], g["y"]
+    tbounds = None if tb is None else [t[0], t[tb]]
+    freq, Pxy, Pxx, Pyy, Cxy, phi, info = P.fft_pwelch(t, x, y, tbounds, plotit=False, verbose=False, **kw)
+    for k in ("nwins", "noverlap", "Navr", "nch"):
+        assert int(getattr(info, k)) == int(g["info_" + k]), k
+    assert list(info.ibnds) == list(g["info_ibnds"])
+    for k in ("S1", "S2", "ENBW", "NENBW", "Fs", "minFreq"):
+        np.testing.assert_allclose(getattr(info, k), g["info_" + k], rtol=1e-12)
+    np.testing.assert_allclose(freq, g["freq"], rtol=1e-12, atol=1e-12)
+    assert Pxx.dtype == np.complex128 and Pxy.dtype == np.complex128
+    # Welch bins: rtol 2e-4 + atol 1e-6*max  (the noise-free self-test signals have > 200 dB of dynamic range in
+    # float64; float32 input quantisation sets the floor there -> atol relative to the peak)
+    for name, got in (("Pxx", Pxx), ("Pyy", Pyy), ("Pxy", Pxy)):
+        ref = g[name]
+        np.testing.assert_allclose(got, ref, rtol=3e-4, atol=2e-6 * np.max(np.abs(ref)), err_msg=name)
+    if tag in ("pwelch_cfg1", "pwelch_reflect", "pwelch_2ch_twosided"):
+        close_rel(Cxy, g["Cxy"], 2e-3, "Cxy")
+        for k in ("Lxx", "Lyy", "Lxy", "Rxx", "Ryy", "Rxy", "corrcoef", "lags", "varPxx", "Ex", "Ey"):
+            close_rel(np.atleast_1d(getattr(info, k)), g["info_" + k], 2e-3, k)
+        # phase where the coherence is significant
+        m = np.abs(g["Cxy"]) > 0.5
+        assert np.max(np.abs(np.angle(np.exp(1j * (phi[m] - g["phi_xy"][m]))))) < 2e-3
+
+
+def test_fft_pwelch_segments(P):
+    g = load_golden("pwelch_cfg1")
+    t, x, y = g["t"], g["x"], g["y"]
+    out = P.fft_pwelch(t, x, y, [t[0], t[-2]], Navr=127, windowoverlap=0.5, windowfunction="Hanning", plotit=False,
+                       segments=True)
+    info = out[-1]
+    close_rel(info.Xfft_seg[:2], g["Xfft_seg_head"], 1e-4, "Xfft_seg")
+    close_rel(info.Pxy_seg[:, :2], g["Pxy_seg_head"], 2e-4, "Pxy_seg")
+
+
+@pytest.mark.parametrize("tag", ["c64_2e16_n4096", "c64_2e14_n1024"])
+def test_fftanal_class_complex(P, tag):
+    g = load_golden("welch_class_" + tag)
+    x = g["x"]
+    t = np.arange(x.size, dtype=np.float64)
+    ft = P.fftanal(t, x, None, tbounds=[t[0], t[-1]], nwins=int(g["nwins"]), windowfunction="Hanning",
+                   windowoverlap=0.5, verbose=False)
+    ft.pwelch()
+    assert ft.Navr == int(g["Navr"]) and ft.noverlap == int(g["noverlap"]) and not ft.onesided
+    for k in ("S1", "S2", "ENBW", "NENBW", "Fs"):
+        np.testing.assert_allclose(getattr(ft, k), g[k], rtol=1e-12)
+    np.testing.assert_allclose(ft.freq, g["freq"], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ft.tseg, g["tseg"], rtol=1e-9)
+    np.testing.assert_allclose(ft.Pxx, g["Pxx"], rtol=2e-4, atol=1e-6 * np.abs(g["Pxx"]).max())
+    np.testing.assert_allclose(ft.varPxx, g["varPxx"], rtol=5e-4, atol=1e-6 * np.abs(g["varPxx"]).max())
+    close_rel(ft.Xseg[:4], g["Xseg_head"], 1e-4, "Xseg")
+    close_rel(ft.Xseg[-2:], g["Xseg_tail"], 1e-4, "Xseg tail")
+    close_rel(ft.Pxx_seg[:2], g["Pxx_seg_head"], 2e-4, "Pxx_seg")
+    close_rel(ft.Xfft, g["Xfft"], 2e-4 * np.abs(g["Xseg_head"]).max() / np.abs(g["Xfft"]).max(), "Xfft")
+    np.testing.assert_allclose(ft.Xpow, g["Xpow"], rtol=1e-4)
+    # averaged spectra only (no [Navr, nfft] arrays): same Pxx
+    ft2 = P.fftanal(t, x, None, tbounds=[t[0], t[-1]], nwins=int(g["nwins"]), windowfunction="Hanning",
+                    windowoverlap=0.5, verbose=False, segments=False)
+    ft2.pwelch()
+    np.testing.assert_allclose(ft2.Pxx, ft.Pxx, rtol=1e-12)
+    assert not hasattr(ft2, "Xseg")
+
+
+@pytest.mark.parametrize("wname", ["Hamming", "SFT3F"])
+def test_fftanal_class_real_xy(P, wname):
+    g = load_golden("welch_class_real_" + wname)
+    t, x, y = g["t"], g["x"], g["y"]
+    ft = P.fftanal(t, x, y, tbounds=[t[0], t[-1]], Navr=31, windowfunction=wname, verbose=False)
+    ft.pwelch()
+    assert ft.onesided and ft.nwins == int(g["nwins"]) and ft.Navr == int(g["Navr"])
+    for k in ("Pxx", "Pyy", "Pxy"):
+        np.testing.assert_allclose(getattr(ft, k), g[k], rtol=3e-4, atol=2e-6 * np.abs(g[k]).max(), err_msg=k)
+    close_rel(ft.Xseg[:3], g["Xseg_head"], 1e-4, "Xseg")
+    close_rel(ft.Yseg[:3], g["Yseg_head"], 1e-4, "Yseg")
+    close_rel(ft.Lxx_seg[:2], g["Lxx_seg_head"], 1e-4, "Lxx_seg")
+    np.testing.assert_allclose(ft.Xpow, g["Xpow"], rtol=2e-4)
+    assert ft.Cxy.shape == ft.Pxy.shape
+
+
+def test_stft_dropin(P):
+    g = load_golden("stft_f32_n2048_ov75")
+    st = P.stft(g["t"], g["x"], tper=2048.5, returnclass=True, windowfunction="Hanning", windowoverlap=0.75)
+    assert st.nwins == 2048 and st.noverlap == 1536 and st.Navr == int(g["Navr"])
+    np.testing.assert_allclose(st.freq, g["freq"], rtol=1e-12)
+    np.testing.assert_allclose(st.tseg, g["tseg"], rtol=1e-9)
+    sc = np.abs(g["Xseg_head"]).max()
+    M = st.Navr
+    assert np.max(np.abs(st.Xseg[:3] - g["Xseg_head"])) <= 1e-4 * sc
+    assert np.max(np.abs(st.Xseg[M // 2:M // 2 + 2] - g["Xseg_mid"])) <= 1e-4 * sc
+    assert np.max(np.abs(st.Xseg[-2:] - g["Xseg_tail"])) <= 1e-4 * sc
+    np.testing.assert_allclose(st.Pxx, g["Pxx"], rtol=3e-4, atol=1e-6 * np.abs(g["Pxx"]).max())
+    g2 = load_golden("stft_tuple_n256")
+    twin, freq, Xseg = P.stft(g2["t"], g2["x"], tper=256.5, returnclass=False, windowfunction="Hamming")
+    np.testing.assert_allclose(twin, g2["twin"], rtol=1e-12)
+    np.testing.assert_allclose(freq, g2["freq"], rtol=1e-12)
+    assert np.max(np.abs(Xseg - g2["Xseg"])) <= 1e-4 * np.abs(g2["Xseg"]).max()
+
+
+def test_specgram_dropin(P):
+    g = load_golden("specgram")
+    time1, f1, sp1 = P.specgram(g["t"], g["s"], wl=512, hanning=True, overlap=True)
+    np.testing.assert_allclose(time1, g["time1"], rtol=1e-12)
+    np.testing.assert_allclose(f1, g["f1"], rtol=1e-12)
+    np.testing.assert_allclose(sp1, g["sp1"], rtol=2e-4, atol=1e-6 * g["sp1"].max())
+    time2, f2, sp2 = P.specgram(g["t"], g["s"], wl=500, hanning=False, overlap=False)     # wl not a power of two
+    np.testing.assert_allclose(time2, g["time2"], rtol=1e-12)
+    np.testing.assert_allclose(sp2, g["sp2"], rtol=3e-4, atol=1e-6 * g["sp2"].max())
+    # windowAverage: block mean of consecutive frames
+    ta, fa, spa = P.specgram(g["t"], g["s"], wl=500, hanning=False, windowAverage=3)
+    nA = g["sp2"].shape[1] // 3
+    np.testing.assert_allclose(spa, g["sp2"][:, :nA * 3].reshape(500, nA, 3).mean(axis=2), rtol=3e-4,
+                               atol=1e-6 * g["sp2"].max())
+
+
+def test_hilbert_dropin(P):
+    g = load_golden("hilbert")
+    for u, z in (("yk", "zk"), ("u_even", "z_even"), ("u_odd", "z_odd"), ("u_2d", "z_2d")):
+        got = P.hilbert(g[u])
+        assert got.shape == g[z].shape and got.dtype == g[z].dtype
+        close_rel(got, g[z], 1e-4, z)
+    close_rel(P.hilbert(g["u_2d"], axes=0), g["z_2d_ax0"], 1e-4, "axis 0")
+    z32 = P.hilbert(g["u_f32"])
+    assert z32.dtype == np.complex64
+    close_rel(z32, g["z_f32"], 1e-4, "f32")
+    close_rel(P.hilbert(g["u_even"][:1000], nfft=1024), g["z_nfft"], 1e-4, "nfft")
+    close_rel(P.hilbert_1d(g["yk"]), g["zk1d"], 1e-5, "1d")
+    close_rel(P.hilbert_1d(g["u_odd"]), g["z_odd_1d"], 1e-4, "1d odd")
+
+
+def test_ccf_dropin(P):
+    g = load_golden("ccf")
+    tau, co = P.ccf(g["x1"], g["x2"], float(g["fs"]))
+    np.testing.assert_allclose(tau, g["tau"], rtol=1e-12)
+    close_rel(co, g["co"], 1e-4, "co")
+    tau2, co2 = P.ccf(g["x3"], g["x4"], 1.0)
+    close_rel(co2, g["co2"], 1e-4, "co2")
+    # ccf.py:139-148: maximum near -phi/(2 pi f) = -138.9 us
+    assert abs(tau[np.argmax(co)] - (-138.9e-6)) < 125e-6
+
+
+def test_fftfilt_and_notch(P):
+    import scipy.signal as ss
+    rng = np.random.default_rng(4)
+    n = 1 << 18
+    k = np.arange(n)
+    x = (rng.standard_normal(n) + 0.3 * np.sin(2 * np.pi * 0.06 * k)).astype(np.float32)
+    h = ss.firwin(513, 0.2)
+    y = P.fftfilt(h, x)
+    ref = ss.lfilter(h.astype(np.float32).astype(np.float64), 1.0, x.astype(np.float64))
+    assert y.dtype == np.float32
+    close_rel(y, ref, 1e-4, "fir")
+    # notch at w0 = 0.12 (f = 0.06 cycles/sample): designed biquad == scipy's, applied as a 513-tap FIR
+    b, a = P.iirnotch(0.12, 5.0)
+    bs, as_ = ss.iirnotch(0.12, 5.0)
+    np.testing.assert_allclose(b, bs, rtol=1e-14); np.testing.assert_allclose(a, as_, rtol=1e-14)
+    yn = P.apply_notch(x, 0.12, 5.0, ntaps=513)
+    exact = ss.lfilter(b, a, x.astype(np.float64))
+    close_rel(yn, exact, 2e-4, "notch vs exact recursion")
+    # the tone is gone: power at f = 0.06 drops by > 40 dB
+    def tone_power(v):
+        return np.abs(np.sum(v[4096:] * np.exp(-2j * np.pi * 0.06 * k[4096:]))) ** 2
+    assert tone_power(yn) < 1e-4 * tone_power(x)
+    # smooth() of the reference == np.convolve(w/sum, reflect-padded, 'valid')
+    from pyfft_amd.filters import smooth
+    s = rng.standard_normal(3000)
+    w = np.hanning(11)
+    pad = np.r_[s[10:0:-1], s, s[-2:-12:-1]]
+    close_rel(smooth(s, 11, "hanning"), np.convolve(w / w.sum(), pad, mode="valid"), 1e-5, "smooth")

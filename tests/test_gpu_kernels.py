@@ -40,6 +40,17 @@ def test_fft_forward_inverse(E, n):
     assert relerr(E.ifft(x), np.fft.ifft(x.astype(np.complex128), axis=-1)) <= 2e-6 * max(1.0, np.sqrt(np.log2(n)))
 
 
+@pytest.mark.parametrize("n", [3, 5, 6, 7, 12, 100, 255, 777, 1000, 1023, 2184, 3640, 4095])
+def test_fft_arbitrary_length(E, n):
+    """Bluestein path (lengths that are not powers of two, e.g. the reference's nwins 1023 / 2184 / 3640)."""
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal((4, n)) + 1j * rng.standard_normal((4, n))).astype(np.complex64)
+    ref = np.fft.fft(x.astype(np.complex128), axis=-1)
+    assert relerr(E.fft(x), ref) <= 4e-6 * max(1.0, np.sqrt(np.log2(n)))
+    assert relerr(E.ifft(E.fft(x)), x) <= 1e-5
+    assert relerr(E.ifft(x), np.fft.ifft(x.astype(np.complex128), axis=-1)) <= 4e-6 * max(1.0, np.sqrt(np.log2(n)))
+
+
 def test_fft_linearity_and_impulse(E):
     n = 4096
     x = np.zeros((3, n), dtype=np.complex64)
@@ -84,13 +95,11 @@ def test_welch_psd_golden_complex(E, tag):
     np.testing.assert_allclose(Pm, ref, rtol=2e-4, atol=1e-6 * ref.max())
 
 
-@pytest.mark.parametrize("wname", ["Hamming"])
+@pytest.mark.parametrize("wname", ["Hamming", "SFT3F"])
 def test_welch_psd_real_onesided(E, wname):
     g = load_golden("welch_class_real_" + wname)
     x = g["x"]
     nfft, nov, M = int(g["nwins"]), int(g["noverlap"]), int(g["Navr"])
-    if nfft & (nfft - 1):
-        pytest.skip("non power-of-two nwins=%d (Bluestein path)" % nfft)
     win = O.windows(wname, nwins=nfft)
     S2 = np.sum(win ** 2)
     P = E.welch_psd(x, win, nfft - nov, M, detrend=True, sided=E.SIDED_ONE, scale=1.0 / (float(g["Fs"]) * S2))
@@ -112,6 +121,69 @@ def test_welch_psd_shapes(E, nfft, hop):
             P = E.welch_psd(x, win, hop, frames, detrend=True, sided=E.SIDED_TWO, scale=1.0)
             ref = O.welch_psd_stream(x, win, nfft, hop, frames, 1.0) * np.sum(win ** 2)
             np.testing.assert_allclose(P, ref, rtol=2e-4, atol=2e-6 * ref.max())
+
+
+@pytest.mark.parametrize("nfft,hop", [(1023, 511), (1001, 250), (3640, 1820), (30, 7), (4095, 4095)])
+def test_welch_psd_arbitrary_length(E, nfft, hop):
+    """non power-of-two and odd segment lengths, one- and two-sided (odd n doubles the last kept bin too)."""
+    rng = np.random.default_rng(nfft)
+    nsig = nfft + hop * 23 + 3
+    x = (rng.standard_normal(nsig) + 0.7).astype(np.float32)
+    M = (nsig - nfft) // hop + 1
+    win = O.windows("Hamming", nwins=nfft)
+    xd = x.astype(np.float64) - x.astype(np.float64).mean()
+    idx = (np.arange(M) * hop)[:, None] + np.arange(nfft)[None, :]
+    P2 = (np.abs(np.fft.fft(win * xd[idx], axis=-1)) ** 2).mean(axis=0)
+    got2 = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+    np.testing.assert_allclose(got2, np.fft.fftshift(P2), rtol=3e-4, atol=2e-6 * P2.max())
+    nny = (nfft + 1) // 2 if nfft % 2 else nfft // 2
+    P1 = P2[:nny].copy()
+    P1[1:-1] *= 2
+    if nfft % 2:
+        P1[-1] *= 2
+    got1 = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_ONE, scale=1.0)
+    assert got1.shape == (nny,)
+    np.testing.assert_allclose(got1, P1, rtol=3e-4, atol=2e-6 * P1.max())
+
+
+def test_welch_linear_detrend(E):
+    rng = np.random.default_rng(5)
+    n, nfft, hop = 50000, 1024, 512
+    k = np.arange(n)
+    x = (np.sin(0.2 * k) + 0.3 * rng.standard_normal(n) + 2.0 + 1e-4 * k).astype(np.float32)
+    M = (n - nfft) // hop + 1
+    win = O.windows("Hanning", nwins=nfft)
+    xd = O.detrend(x.astype(np.float64), -1)
+    ref = O.welch_psd_stream(xd, win, nfft, hop, M, 1.0, detrend_style=0) * np.sum(win ** 2)
+    got = E.welch_psd(x, win, hop, M, detrend="linear", sided=E.SIDED_TWO, scale=1.0)
+    np.testing.assert_allclose(got, ref, rtol=5e-4, atol=3e-6 * ref.max())
+    z = (x + 1j * (0.5 * x[::-1] - 3e-5 * k)).astype(np.complex64)
+    zd = O.detrend(z.astype(np.complex128).real, -1) + 1j * O.detrend(z.astype(np.complex128).imag, -1)
+    refz = O.welch_psd_stream(zd, win, nfft, hop, M, 1.0, detrend_style=0) * np.sum(win ** 2)
+    gotz = E.welch_psd(z, win, hop, M, detrend="linear", sided=E.SIDED_TWO, scale=1.0)
+    np.testing.assert_allclose(gotz, refz, rtol=5e-4, atol=3e-6 * refz.max())
+
+
+def test_welch_carry_vs_generic_kernel(E):
+    """the register-carried metric kernel and the generic kernel are the same function"""
+    import os
+    rng = np.random.default_rng(12)
+    for nfft, hop in ((4096, 2048), (2048, 512), (1024, 1024), (256, 64)):
+        nsig = nfft + hop * 301
+        x = (rng.standard_normal(nsig) + 1j * rng.standard_normal(nsig) + (0.2 + 0.1j)).astype(np.complex64)
+        M = (nsig - nfft) // hop + 1
+        win = O.windows("Hanning", nwins=nfft)
+        a = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+        assert E.profile_last_kernel() == "k_welch_carry"
+        os.environ["SP_WELCH_GENERIC"] = "1"
+        try:
+            b = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+            assert E.profile_last_kernel() == "k_welch"
+        finally:
+            del os.environ["SP_WELCH_GENERIC"]
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-7 * b.max())
+        ref = O.welch_psd_stream(x, win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+        np.testing.assert_allclose(a, ref, rtol=2e-4, atol=1e-6 * ref.max())
 
 
 def test_welch_errors(E):
@@ -216,6 +288,11 @@ def test_hilbert_rows(E):
     assert np.max(np.abs(zp - g["z_nfft"])) <= 1e-4 * np.abs(g["z_nfft"]).max()
     # real part of the analytic signal is the input
     assert np.max(np.abs(z.real - g["u_even"])) < 1e-5 * np.abs(g["u_even"]).max()
+    # odd length: the reference leaves bin (N+1)/2 un-zeroed (differs from scipy) -- reproduced
+    zo = E.hilbert_rows(g["u_odd"][None, :], g["u_odd"].size)[0]
+    assert np.max(np.abs(zo - g["z_odd"])) <= 1e-4 * np.abs(g["z_odd"]).max()
+    z6 = E.hilbert_rows(np.ascontiguousarray(g["u_2d"].T), 6)           # tiny non power-of-two rows
+    assert np.max(np.abs(z6.T - g["z_2d_ax0"])) <= 1e-4 * np.abs(g["z_2d_ax0"]).max()
 
 
 # ---------------------------------------------------------------- A11 ccf

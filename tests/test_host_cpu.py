@@ -1,0 +1,117 @@
+"""CPU-only checks of the product's host side: window tables and geometry against the golden fixtures, the notch
+design, that libspectral.so loads and exports every symbol include/spectral.h declares, and that the product
+fails loudly (no CPU fallback) when no GPU is present.  No compute calls into the library here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, have_gpu
+
+import pyfft_amd
+from pyfft_amd import _ffi
+from pyfft_amd import fft_analysis as FA
+from pyfft_amd.windows import windows
+
+WNAMES = ["Hanning", "Hamming", "Blackman", "SFT3F", "SFT4F", "SFT5F", "SFT3M", "SFT4M", "SFT5M", "Nuttall3a",
+          "Nuttall3b", "Nuttall3", "Nuttall4a", "Nuttall4b", "Nuttall4c", "Nuttall4", "Kaiser", "Welch", "Bartlett",
+          "box"]
+
+
+@pytest.mark.parametrize("name", WNAMES)
+def test_product_windows_match_reference(name):
+    g = load_golden("windows")
+    kw = {"beta": 8.6} if name == "Kaiser" else {}
+    for N in (16, 255, 1024):
+        np.testing.assert_allclose(windows(name, nwins=N, verbose=False, **kw), g["%s_per_%d" % (name, N)], rtol=1e-13,
+                                   atol=1e-15)
+        np.testing.assert_allclose(windows(name, nwins=N, periodic=False, verbose=False, **kw),
+                                   g["%s_sym_%d" % (name, N)], rtol=1e-13, atol=1e-15)
+    assert windows(name, verbose=False, **kw) == float(g["%s_rov" % name])
+    val, (label, _) = windows(name, nwins=8, verbose=False, msgout=True, **kw)
+    assert len(val) == 8 and isinstance(label, str)
+
+
+def test_product_geometry_matches_reference():
+    g = load_golden("geometry")
+    for nsig, Navr, ov, nw, no, na, nyq in g["table"]:
+        nwins = FA._nwins(int(nsig), int(Navr), ov)
+        assert nwins == int(nw)
+        assert FA._noverlap(nwins, ov) == int(no)
+        assert FA._navr(int(nsig), nwins, int(no)) == int(na)
+        assert FA._nnyquist(nwins) == int(nyq)
+        assert FA.fftanal._getNwins(int(nsig), int(Navr), ov) == int(nw)
+    np.testing.assert_allclose(np.array(FA._norms(windows("Hanning", nwins=4096, verbose=False), 2048, 1.0)),
+                               g["hann4096_norms"], rtol=1e-13)
+
+
+def test_fftanal_init_geometry_without_gpu():
+    g = load_golden("welch_class_c64_2e16_n4096")
+    x = g["x"]
+    t = np.arange(x.size, dtype=np.float64)
+    ft = pyfft_amd.fftanal(t, x, None, tbounds=[t[0], t[-1]], nwins=4096, windowfunction="Hanning", windowoverlap=0.5,
+                           verbose=False)
+    assert (ft.nwins, ft.noverlap, ft.Navr, ft.Nnyquist) == (4096, 2048, int(g["Navr"]), 2048)
+    assert not ft.onesided
+    for k in ("S1", "S2", "ENBW", "NENBW", "Fs"):
+        np.testing.assert_allclose(getattr(ft, k), g[k], rtol=1e-13)
+    # tper path truncates like the reference (Q5)
+    ft2 = pyfft_amd.fftanal(t, x, None, tper=4096.0 * (1 - 1e-12), verbose=False)
+    assert ft2.nwins == 4095
+
+
+def test_notch_design_matches_reference():
+    g = load_golden("notch")
+    b, a = pyfft_amd.iirnotch(60.0 / 100.0, 30.0)
+    np.testing.assert_allclose(b, g["b_doc"], rtol=1e-14)
+    np.testing.assert_allclose(a, g["a_doc"], rtol=1e-14)
+    for row in g["sweep"]:
+        bn, an = pyfft_amd.iirnotch(row[0], row[1])
+        bp, ap = pyfft_amd.iirpeak(row[0], row[1])
+        np.testing.assert_allclose(np.concatenate([bn, an, bp, ap]), row[2:], rtol=1e-13, atol=1e-16)
+    with pytest.raises(ValueError):
+        pyfft_amd.iirnotch(-0.1, 3.0)
+    from pyfft_amd.notch_filter import impulse_response
+    import scipy.signal as ss
+    h = impulse_response(b, a, 40)
+    np.testing.assert_allclose(h, ss.lfilter(b, a, np.r_[1.0, np.zeros(39)]), rtol=1e-11, atol=1e-14)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "spectral.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 18
+    assert declared == set(_ffi.SIGNATURES), (declared ^ set(_ffi.SIGNATURES))
+    lib = ctypes.CDLL(_ffi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _ffi.load_library().sp_version() >= 100
+    assert _ffi.lib().sp_max_wg_fft() == 8192
+
+
+def test_export_list_mirrors_reference_package():
+    for name in ("fft", "fft_pwelch", "fftanal", "windows", "specgram", "stft", "hilbert", "hilbert_1d", "ccf",
+                 "iirnotch", "iirpeak", "fftfilt", "apply_notch", "Cxy_Cxy2"):
+        assert hasattr(pyfft_amd, name), name
+    assert pyfft_amd.fft is pyfft_amd.fft_analysis
+
+
+@pytest.mark.skipif(have_gpu(), reason="needs a box without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    with pytest.raises(_ffi.SpectralError, match="no HIP device"):
+        pyfft_amd.engine.fft(np.zeros(8, dtype=np.complex64))
+    with pytest.raises(_ffi.SpectralError):
+        pyfft_amd.hilbert(np.zeros(16))
+    with pytest.raises(_ffi.SpectralError):
+        pyfft_amd.ccf(np.zeros(16), np.ones(16), 1.0)
+
+
+def test_unsupported_branches_raise():
+    t = np.arange(100.0)
+    with pytest.raises(NotImplementedError):
+        pyfft_amd.fft_pwelch(t, np.zeros(100), np.zeros(100), useMLAB=True)
+    with pytest.raises(NotImplementedError):
+        pyfft_amd.fft_pwelch(t, np.zeros(50), np.zeros(100))       # nT-model branch
