@@ -77,6 +77,18 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
                  int64_t nframes, int detrend, double mean_re, double mean_im, int sided,
                  double scale, double *pxx_out, int mem);
 
+/* ---- the same path split in two for segment-sharded multi-process runs (one process per GPU): every process
+ *      accumulates its own frames against a local estimate of the mean, the processes all-reduce sum_out (2 doubles)
+ *      to get the global mean of the stream, and each finishes with it; the finished spectra (scaled by
+ *      scale/frames_total) then add up to the Welch PSD of the whole stream.  Needs a power-of-two nfft in
+ *      [256, sp_max_wg_fft()] with hop = nfft/4, nfft/2 or nfft.  One accumulation may be pending at a time; x must
+ *      stay valid until sp_welch_finish when mem=1.
+ *      nmean: this shard's own samples x[0:nmean] (halo excluded) -> sum_out[2] = sum of them.
+ *      mean: [2] doubles (host if mem=0, device if mem=1), or NULL = the shard's own mean sum_out/nmean. */
+int sp_welch_accum(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+                   int64_t nmean, double *sum_out, int mem);
+int sp_welch_finish(const double *mean, int64_t frames_total, int sided, double scale, double *pxx_out, int mem);
+
 /* ---- A5: fft_pwelch numeric core (fft_analysis.py:339-446): reference x against nch
  *      channels y[c][0:nsig] (channel-major, row stride y_ld samples).
  *      pxx[nbins], pyy[nch][nbins], pxy[nch][nbins] complex (re,im doubles) = Y_c * conj(X)

@@ -1,17 +1,28 @@
-// k_welch.hip -- fused Welch PSD launchers (generic + register-carried metric kernel)
+// k_welch.hip -- fused Welch PSD launchers (generic + register-carried metric kernel + one-pass detrend epilogue)
 #include "launch.h"
 namespace sp {
 
+bool welch_carry_eligible(const Xf &xf, int hop, bool lin) {
+    if (xf.blue || lin || xf.L < 256 || xf.L > 8192) return false;
+    const int T = xf.L / 16;
+    if (hop % T != 0) return false;
+    const int shift = hop / T;
+    return shift == 4 || shift == 8 || shift == 16;
+}
+
 template <int N, bool CPLX>
 static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int64_t nframes, const float *trend,
-                      const Xf &xf, float *partial, const RunPart &rp) {
+                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial) {
     using C = WgCfg<N>;
-    if (hop % C::T != 0) return false;
     const int shift = hop / C::T;
 #define CARRY_(S)                                                                                     \
     case S:                                                                                           \
-        hipLaunchKernelGGL((k_welch_carry<N, CPLX, S>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(1), c.stream, x, win, \
-                           nframes, rp.fpg, trend, xf.tb, partial);                                   \
+        if (spartial)                                                                                 \
+            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(1), c.stream, \
+                               x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(1), c.stream, \
+                               x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
         return true;
     switch (shift) {
         CARRY_(4) CARRY_(8) CARRY_(16)
@@ -21,14 +32,15 @@ static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int
 }
 
 int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
-                 bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, const char **kname) {
+                 bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, cf *spartial,
+                 const char **kname) {
     if (kname) *kname = "k_welch";
-    if (allow_carry && !lin && !xf.blue) {
+    if (allow_carry && welch_carry_eligible(xf, hop, lin)) {
         bool done = false;
 #define TRY_(NN)                                                                                      \
     case NN:                                                                                          \
-        done = cplx ? try_carry<NN, true>(c, x, win, hop, nframes, trend, xf, partial, rp)            \
-                    : try_carry<NN, false>(c, x, win, hop, nframes, trend, xf, partial, rp);          \
+        done = cplx ? try_carry<NN, true>(c, x, win, hop, nframes, trend, xf, partial, rp, spartial)  \
+                    : try_carry<NN, false>(c, x, win, hop, nframes, trend, xf, partial, rp, spartial); \
         break;
         switch (xf.L) {
             TRY_(256) TRY_(512) TRY_(1024) TRY_(2048) TRY_(4096) TRY_(8192)
@@ -36,10 +48,11 @@ int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int ho
         }
 #undef TRY_
         if (done) {
-            if (kname) *kname = "k_welch_carry";
+            if (kname) *kname = spartial ? "k_welch_carry(onepass)" : "k_welch_carry";
             return 0;
         }
     }
+    if (spartial) return -1;      // one-pass accumulation exists only in the carry kernel
 #define M_(XT)                                                                                        \
     if (cplx) {                                                                                       \
         if (lin) hipLaunchKernelGGL((k_welch<XT, true, true>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), \
@@ -61,6 +74,39 @@ int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &
     const int n = xf.tb.n;
     hipLaunchKernelGGL(k_welch_finish, dim3((n + SP_FIN_BINS - 1) / SP_FIN_BINS), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
                        c.stream, partial, G, xf.L, n, sided, scale, out);
+    return 0;
+}
+
+// ---- one-pass detrend epilogue ------------------------------------------------------------------
+int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, float *trend) {
+    if (cplx) hipLaunchKernelGGL((k_op_estimate<true>), dim3(1), dim3(1024), 0, c.stream, x, nsig, trend);
+    else hipLaunchKernelGGL((k_op_estimate<false>), dim3(1), dim3(1024), 0, c.stream, x, nsig, trend);
+    return 0;
+}
+
+// A[k] raw sums, Sl[j] block sums, tot = sum_{i<nmean}(x - mu0)
+int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *partial, const cf *spartial,
+                     int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st) {
+    const int N = xf.L, H = hop, r = N / H;
+    hipLaunchKernelGGL(k_welch_finish, dim3((N + SP_FIN_BINS - 1) / SP_FIN_BINS), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
+                       c.stream, partial, G, N, N, (int)SIDED_RAW, 1.0, st.A);
+    hipLaunchKernelGGL(k_op_reduce_s, dim3((H + 63) / 64), dim3(1024), 0, c.stream, spartial, G, H, st.Sl);
+    if (cplx) hipLaunchKernelGGL((k_op_total<true>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot);
+    else hipLaunchKernelGGL((k_op_total<false>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot);
+    return 0;
+}
+
+// dlt, cw = w*c, B = FFT(cw) (in place), combine -> out
+int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, OnePass st,
+                     const double *mean_in, int64_t nmean, const Xf &xf, int hop, int64_t nframes, cf *cw, const cf *Wf,
+                     int sided, double scale, double *out) {
+    const int N = xf.L, H = hop, r = N / H;
+    hipLaunchKernelGGL(k_op_delta, dim3(1), dim3(64), 0, c.stream, st.tot, nmean, mean_in, trend, st.dlt);
+    if (cplx) hipLaunchKernelGGL((k_op_cw<true>), dim3((N + 255) / 256), dim3(256), 0, c.stream, x, trend, win, st.Sl, N, H, r, nframes, cw);
+    else hipLaunchKernelGGL((k_op_cw<false>), dim3((N + 255) / 256), dim3(256), 0, c.stream, x, trend, win, st.Sl, N, H, r, nframes, cw);
+    if (launch_fft_c2c(c, cw, cw, 1, 0, xf)) return -1;
+    hipLaunchKernelGGL(k_op_combine, dim3((N + 255) / 256), dim3(256), 0, c.stream, st.A, cw, Wf, st.dlt, N, nframes, sided,
+                       scale, out);
     return 0;
 }
 

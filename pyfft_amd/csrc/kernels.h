@@ -203,37 +203,53 @@ __global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, 
 // slots), so a frame advances by renaming registers: the overlapped part of the next frame is
 // carried in registers and only the SHIFT new slots per thread are read from HBM -- every sample
 // is fetched once -- and those loads are issued one frame ahead of their use (software prefetch).
+// The detrend constant is subtracted once per sample when it arrives.
+//
+// ONEPASS (global-mean detrend without a separate pass over the signal): `trend` holds an ESTIMATE
+// mu0 of the mean; the kernel additionally accumulates, per group, the sum over its frames of the
+// frame's last hop-block (time domain, SHIFT slots).  From those block sums the epilogue rebuilds
+// sum_g X_g[k] and the exact mean and applies  |X - dW|^2 = |X|^2 - 2Re(conj(dW) X) + |dW|^2.
 // ------------------------------------------------------------------------------------------
-template <int N, bool CPLX, int SHIFT>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(const void *__restrict__ x, const float *__restrict__ win,
-                                                               int64_t nframes, int64_t fpg,
-                                                               const float *__restrict__ trend, XfTables tb,
-                                                               float *__restrict__ partial) {
+template <int N, bool CPLX, int SHIFT, bool ONEPASS>
+__global__ __launch_bounds__(WgCfg<N>::WG, WgCfg<N>::WG == 256 ? 3 : 2) void k_welch_carry(
+    const void *__restrict__ x, const float *__restrict__ win, int64_t nframes, int64_t fpg,
+    const float *__restrict__ trend, XfTables tb, float *__restrict__ partial, cf *__restrict__ spartial) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
     static_assert(SHIFT >= 1 && SHIFT <= C::R, "hop must be 1..R register slots");
     constexpr int KEEP = C::R - SHIFT;
+    constexpr bool UNI = C::FPW == 1;          // one group per workgroup: trip counts may differ between groups
     const int hop = SHIFT * C::T;
     float w[C::R], acc[C::R];
+    cf sacc[SHIFT];
 #pragma unroll
     for (int t = 0; t < C::R; ++t) {
         w[t] = win[tid + C::T * t];
         acc[t] = 0.f;
     }
+#pragma unroll
+    for (int s = 0; s < SHIFT; ++s) sacc[s] = mk(0.f, 0.f);
     const cf mu = load_trend(trend).m;
     const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
     const int64_t g0 = gid * fpg;
     const int64_t last = nframes - 1;
+    int64_t trips = fpg;
+    if (UNI) {
+        trips = nframes - g0;
+        trips = trips < 0 ? 0 : (trips > fpg ? fpg : trips);
+    }
     cf raw[C::R];
     {
         const int64_t base = (g0 < nframes ? g0 : last) * hop + tid;
 #pragma unroll
         for (int t = 0; t < C::R; ++t) raw[t] = load_sample(x, base + C::T * t, CPLX);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) raw[t] = raw[t] - mu;
     }
-    for (int64_t i = 0; i < fpg; ++i) {
+    for (int64_t i = 0; i < trips; ++i) {
         const int64_t g = g0 + i;
-        const float keep = g < nframes ? 1.f : 0.f;
+        const float keep = (UNI || g < nframes) ? 1.f : 0.f;
         // prefetch the SHIFT new slots of frame g+1 (clamped at the end of the signal; unused then)
         cf nx[SHIFT];
         {
@@ -242,20 +258,195 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(const void *__rest
 #pragma unroll
             for (int s = 0; s < SHIFT; ++s) nx[s] = load_sample(x, base + C::T * s, CPLX);
         }
+        if (ONEPASS) {
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) sacc[s] = UNI ? sacc[s] + raw[KEEP + s] : sacc[s] + keep * raw[KEEP + s];
+        }
         cf v[C::R];
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) v[t] = w[t] * (raw[t] - mu);
+        for (int t = 0; t < C::R; ++t) v[t] = w[t] * raw[t];
         xf.fwd(v, lds, tid, N);
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) acc[t] += keep * cnorm(v[t]);
-        // advance one hop: rename registers
+        for (int t = 0; t < C::R; ++t) acc[t] = UNI ? acc[t] + cnorm(v[t]) : acc[t] + keep * cnorm(v[t]);
+        // advance one hop: rename registers, detrend the samples that just arrived
 #pragma unroll
         for (int t = 0; t < KEEP; ++t) raw[t] = raw[t + SHIFT];
 #pragma unroll
-        for (int s = 0; s < SHIFT; ++s) raw[KEEP + s] = nx[s];
+        for (int s = 0; s < SHIFT; ++s) raw[KEEP + s] = nx[s] - mu;
     }
 #pragma unroll
     for (int t = 0; t < C::R; ++t) partial[gid * N + tid + C::T * t] = acc[t];
+    if (ONEPASS) {
+#pragma unroll
+        for (int s = 0; s < SHIFT; ++s) spartial[gid * hop + tid + C::T * s] = sacc[s];
+    }
+}
+
+// ---- one-pass detrend epilogue (all tiny, double precision) -------------------------------------
+// state layout (doubles): A[N] | Sl[2*H] | tot[2] = sum_{i<nmean}(x[i]-mu0) | dlt[2] = mean - mu0 | cnt[1]
+struct OnePass {
+    double *A, *Sl, *tot, *dlt;
+};
+
+// Sl[j] = sum over groups of spartial[g][j]  (complex, H entries); 64 entries x 16 slices per block
+static __global__ __launch_bounds__(1024) void k_op_reduce_s(const cf *__restrict__ sp, int64_t G, int H,
+                                                              double *__restrict__ Sl) {
+    __shared__ double sh[2][16][64];
+    const int lane = threadIdx.x % 64, sl = threadIdx.x / 64;
+    const int j = blockIdx.x * 64 + lane;
+    double a = 0, b = 0;
+    if (j < H)
+        for (int64_t g = sl; g < G; g += 16) {
+            const cf v = sp[g * H + j];
+            a += v.x;
+            b += v.y;
+        }
+    sh[0][sl][lane] = a;
+    sh[1][sl][lane] = b;
+    __syncthreads();
+    if (sl == 0 && j < H) {
+        double ta = 0, tb = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            ta += sh[0][q][lane];
+            tb += sh[1][q][lane];
+        }
+        Sl[2 * j] = ta;
+        Sl[2 * j + 1] = tb;
+    }
+}
+
+// tot = sum_{i < nmean} (x[i] - mu0): block sums cover [(r-1)H, (M+r-1)H); add the head blocks and fix the end.
+// one block of 1024 threads.
+template <bool CPLX>
+static __global__ __launch_bounds__(1024) void k_op_total(const void *__restrict__ x, const float *__restrict__ trend,
+                                                           const double *__restrict__ Sl, int H, int r, int64_t M,
+                                                           int64_t nmean, double *__restrict__ tot) {
+    __shared__ double sh[2][1024];
+    const cf mu = mk(trend[0], trend[1]);
+    double a = 0, b = 0;
+    for (int j = threadIdx.x; j < H; j += 1024) {
+        a += Sl[2 * j];
+        b += Sl[2 * j + 1];
+    }
+    const int64_t head = (int64_t)(r - 1) * H;           // samples before the first counted block
+    const int64_t cov = (M + r - 1) * (int64_t)H;        // end of the last counted block
+    for (int64_t i = threadIdx.x; i < head; i += 1024) {
+        const cf v = load_sample(x, i, CPLX) - mu;
+        a += v.x;
+        b += v.y;
+    }
+    if (nmean > cov) {
+        for (int64_t i = cov + threadIdx.x; i < nmean; i += 1024) {
+            const cf v = load_sample(x, i, CPLX) - mu;
+            a += v.x;
+            b += v.y;
+        }
+    } else {
+        for (int64_t i = nmean + threadIdx.x; i < cov; i += 1024) {
+            const cf v = load_sample(x, i, CPLX) - mu;
+            a -= v.x;
+            b -= v.y;
+        }
+    }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        tot[0] = sh[0][0];
+        tot[1] = sh[1][0];
+    }
+}
+
+// dlt = mean - mu0, with mean either given (mean_in != null: global mean from the caller) or tot/nmean
+static __global__ void k_op_delta(const double *__restrict__ tot, int64_t nmean, const double *__restrict__ mean_in,
+                                  const float *__restrict__ trend, double *__restrict__ dlt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (mean_in) {
+            dlt[0] = mean_in[0] - (double)trend[0];
+            dlt[1] = mean_in[1] - (double)trend[1];
+        } else {
+            dlt[0] = tot[0] / (double)nmean;
+            dlt[1] = tot[1] / (double)nmean;
+        }
+    }
+}
+
+// cw[n] = w[n] * c[n],  c[qH+j] = Sl[j] + sum_{b=q}^{r-2} xb[j] - sum_{b=M+q}^{M+r-2} xb[j]   (xb = x - mu0, block b)
+template <bool CPLX>
+static __global__ void k_op_cw(const void *__restrict__ x, const float *__restrict__ trend, const float *__restrict__ win,
+                               const double *__restrict__ Sl, int N, int H, int r, int64_t M, cf *__restrict__ cw) {
+    const int nidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (nidx >= N) return;
+    const cf mu = mk(trend[0], trend[1]);
+    const int q = nidx / H, j = nidx % H;
+    double a = Sl[2 * j], b = Sl[2 * j + 1];
+    for (int bb = q; bb <= r - 2; ++bb) {
+        const cf v = load_sample(x, (int64_t)bb * H + j, CPLX) - mu;
+        a += v.x;
+        b += v.y;
+    }
+    for (int64_t bb = M + q; bb <= M + r - 2; ++bb) {
+        const cf v = load_sample(x, bb * H + j, CPLX) - mu;
+        a -= v.x;
+        b -= v.y;
+    }
+    const double wn = (double)win[nidx];
+    cw[nidx] = mk((float)(wn * a), (float)(wn * b));
+}
+
+// out[slot] = scale * doubling * (A[k] - 2 Re(conj(d Wf[k]) B[k]) + M |d Wf[k]|^2)
+static __global__ void k_op_combine(const double *__restrict__ A, const cf *__restrict__ B, const cf *__restrict__ Wf,
+                                    const double *__restrict__ dlt, int N, int64_t M, int sided, double scale,
+                                    double *__restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const int slot = bin_slot(k, N, sided);
+    if (slot < 0) return;
+    const double dr = dlt[0], di = dlt[1];
+    const double wr = Wf[k].x, wi = Wf[k].y;
+    const double er = dr * wr - di * wi, ei = dr * wi + di * wr;       // d * Wf[k]
+    const double br = B[k].x, bi = B[k].y;
+    const double p = A[k] - 2.0 * (er * br + ei * bi) + (double)M * (er * er + ei * ei);
+    out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
+}
+
+// mean estimate from <= 65536 samples spread over the whole signal -> trend[4] = (mu0, 0 slope). one block.
+template <bool CPLX>
+static __global__ __launch_bounds__(1024) void k_op_estimate(const void *__restrict__ x, int64_t nsig,
+                                                              float *__restrict__ trend) {
+    __shared__ double sh[2][1024];
+    const int64_t cnt = nsig < 65536 ? nsig : 65536;
+    const int64_t stride = nsig / cnt;
+    double a = 0, b = 0;
+    for (int64_t i = threadIdx.x; i < cnt; i += 1024) {
+        const cf v = load_sample(x, i * stride, CPLX);
+        a += v.x;
+        b += v.y;
+    }
+    sh[0][threadIdx.x] = a;
+    sh[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+            sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        trend[0] = (float)(sh[0][0] / (double)cnt);
+        trend[1] = (float)(sh[1][0] / (double)cnt);
+        trend[2] = 0.f;
+        trend[3] = 0.f;
+    }
 }
 
 // sum partial[G][L] over G in double, apply sidedness + scale -> out[nbins] (double).

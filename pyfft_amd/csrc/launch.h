@@ -50,8 +50,16 @@ inline int strided_blocks(int L, int64_t items, int ncu) {
 
 // every launcher returns 0 or -1 (unsupported L); kernel launch errors surface through hipGetLastError
 int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf);
+bool welch_carry_eligible(const Xf &xf, int hop, bool lin);
 int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
-                 bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, const char **kname);
+                 bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, cf *spartial,
+                 const char **kname);
+int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, float *trend);
+int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *partial, const cf *spartial,
+                     int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st);
+int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, OnePass st,
+                     const double *mean_in, int64_t nmean, const Xf &xf, int hop, int64_t nframes, cf *cw, const cf *Wf,
+                     int sided, double scale, double *out);
 int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int sided, double scale, double *out);
 int launch_csd(LaunchCtx c, const void *x, const void *y, bool cplx, int nch, int64_t y_ld, const float *win, int hop,
                int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,

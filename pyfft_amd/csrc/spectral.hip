@@ -76,7 +76,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     std::map<int64_t, cf *> twiddles;   // L -> exp(-2 pi i m/L)
     std::map<int64_t, BlueTab> blue;    // n -> Bluestein tables
-    Scratch in0, in1, out0, work, small, trends;
+    Scratch in0, in1, out0, work, small, trends, onepass;
     std::mutex mu;
     bool profile = false, prof_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -84,6 +84,29 @@ struct Ctx {
 } g;
 
 LaunchCtx lc() { return LaunchCtx{g.stream, g.ncu}; }
+
+// pending one-pass Welch accumulation (sp_welch_accum -> sp_welch_finish)
+struct Pending {
+    bool valid = false;
+    const void *xd = nullptr;
+    bool cplx = false;
+    int64_t nsig = 0, nframes = 0, nmean = 0;
+    int nfft = 0, hop = 0;
+    Xf xf;
+    const float *win_d = nullptr;
+    const cf *Wf = nullptr;
+    OnePass st;
+    float *trend_f = nullptr;
+    cf *cw = nullptr;
+    double *sum_d = nullptr;
+} g_pend;
+
+__global__ void k_op_sum(const double *tot, const float *trend, int64_t nmean, double *sum_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        sum_out[0] = tot[0] + (double)nmean * (double)trend[0];
+        sum_out[1] = tot[1] + (double)nmean * (double)trend[1];
+    }
+}
 
 struct ProfScope {   // brackets one kernel launch with HIP events on the launch stream when profiling is on
     bool on;
@@ -287,6 +310,81 @@ bool env_flag(const char *name) {
     return v && v[0] && v[0] != '0';
 }
 
+
+// ---- one-pass Welch: accumulate, then finish with a (possibly global) mean ------------------------
+int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+                       int64_t nmean) {
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
+    if (!welch_carry_eligible(xf, hop, false))
+        return fail("one-pass Welch needs a power-of-two nfft in [256, %d] and hop = nfft/4, nfft/2 or nfft (got nfft=%d hop=%d)",
+                    SP_MAX_WG_FFT, nfft, hop);
+    if (nmean < 1 || nmean > nsig) return fail("sp_welch_accum: nmean must be in [1, nsig]");
+    void *win_d;
+    if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
+    // Wf = FFT(window), cached with the window
+    std::vector<cf> wc((size_t)nfft);
+    for (int i = 0; i < nfft; ++i) wc[(size_t)i] = make_float2(win[i], 0.f);
+    void *Wf_d;
+    bool fresh = false;
+    if (get_table(3, wc.data(), sizeof(cf) * (size_t)nfft, &Wf_d, &fresh)) return -1;
+    if (fresh) LAUNCHCHK(launch_fft_c2c(lc(), (const cf *)Wf_d, (cf *)Wf_d, 1, 0, xf));
+    TrendBuf tb;
+    if (get_trendbuf(1, &tb)) return -1;
+    const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+    if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
+    const size_t sp_bytes = sizeof(cf) * (size_t)rp.groups * (size_t)hop;
+    const size_t st_doubles = (size_t)nfft + 2 * (size_t)hop + 8;
+    const size_t sp_pad = (sp_bytes + 255) & ~(size_t)255;
+    const size_t st_pad = (sizeof(double) * st_doubles + 255) & ~(size_t)255;
+    if (g.onepass.ensure(sp_pad + st_pad + sizeof(cf) * (size_t)nfft)) return -1;
+    cf *spartial = (cf *)g.onepass.p;
+    double *stp = (double *)((char *)g.onepass.p + sp_pad);
+    OnePass st;
+    st.A = stp;
+    st.Sl = stp + nfft;
+    st.tot = st.Sl + 2 * (size_t)hop;
+    st.dlt = st.tot + 2;
+    double *sum_d = st.dlt + 2;
+    cf *cw = (cf *)((char *)g.onepass.p + sp_pad + st_pad);
+    float *partial = (float *)g.work.p;
+    LAUNCHCHK(launch_op_estimate(lc(), xd, cplx, nsig, tb.f));
+    {
+        ProfScope ps;
+        LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,
+                               spartial, &g.last_kernel));
+    }
+    LAUNCHCHK(launch_op_reduce(lc(), xd, cplx, tb.f, partial, spartial, rp.groups, xf, hop, nframes, nmean, st));
+    hipLaunchKernelGGL(k_op_sum, dim3(1), dim3(64), 0, g.stream, st.tot, tb.f, nmean, sum_d);
+    HIPCHK(hipGetLastError());
+    g_pend.valid = true;
+    g_pend.xd = xd;
+    g_pend.cplx = cplx;
+    g_pend.nsig = nsig;
+    g_pend.nframes = nframes;
+    g_pend.nmean = nmean;
+    g_pend.nfft = nfft;
+    g_pend.hop = hop;
+    g_pend.xf = xf;
+    g_pend.win_d = (const float *)win_d;
+    g_pend.Wf = (const cf *)Wf_d;
+    g_pend.st = st;
+    g_pend.trend_f = tb.f;
+    g_pend.cw = cw;
+    g_pend.sum_d = sum_d;
+    return 0;
+}
+
+int welch_finish_locked(const double *mean_d /*device or null*/, int64_t frames_total, int sided, double scale,
+                        double *out_d) {
+    if (!g_pend.valid) return fail("sp_welch_finish: no pending sp_welch_accum");
+    g_pend.valid = false;
+    LAUNCHCHK(launch_op_finish(lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, mean_d, g_pend.nmean,
+                               g_pend.xf, g_pend.hop, g_pend.nframes, g_pend.cw, g_pend.Wf, sided,
+                               scale / (double)frames_total, out_d));
+    return 0;
+}
+
 }   // namespace
 
 // ------------------------------------------------------------------------------------------
@@ -338,6 +436,8 @@ void sp_shutdown(void) {
     g.work.release();
     g.small.release();
     g.trends.release();
+    g.onepass.release();
+    g_pend.valid = false;
     tables_release();
     g.ready = false;
 }
@@ -459,26 +559,83 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         HIPCHK(hipMemcpyAsync(g.in0.p, x, esz * (size_t)nsig, hipMemcpyHostToDevice, g.stream));
         xd = g.in0.p;
     }
-    void *win_d;
-    if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
-    TrendBuf tb;
-    if (get_trendbuf(1, &tb)) return -1;
-    if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
     const int nb = nbins_host(nfft, sided);
     double *out_d = pxx_out;
     if (!mem) {
         if (g.out0.ensure(sizeof(double) * (size_t)nb)) return -1;
         out_d = (double *)g.out0.p;
     }
-    const RunPart rp = run_partition(xf.L, nframes, g.ncu);
-    if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
-    float *partial = (float *)g.work.p;
-    {
-        ProfScope ps;
-        LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, partial, rp,
-                               !env_flag("SP_WELCH_GENERIC"), &g.last_kernel));
+    const bool allow_carry = !env_flag("SP_WELCH_GENERIC");
+    if (detrend == SP_DETREND_MEAN && allow_carry && !env_flag("SP_WELCH_TWOPASS") && welch_carry_eligible(xf, hop, false)) {
+        // global-mean detrend in ONE pass over the signal (estimate + exact correction in the epilogue)
+        if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nsig)) return -1;
+        if (welch_finish_locked(nullptr, nframes, sided, scale, out_d)) return -1;
+    } else {
+        void *win_d;
+        if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
+        TrendBuf tb;
+        if (get_trendbuf(1, &tb)) return -1;
+        if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
+        const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+        if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
+        float *partial = (float *)g.work.p;
+        {
+            ProfScope ps;
+            LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, partial, rp,
+                                   allow_carry, nullptr, &g.last_kernel));
+        }
+        LAUNCHCHK(launch_welch_finish(lc(), partial, rp.groups, xf, sided, scale / (double)nframes, out_d));
     }
-    LAUNCHCHK(launch_welch_finish(lc(), partial, rp.groups, xf, sided, scale / (double)nframes, out_d));
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(pxx_out, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
+}
+
+int sp_welch_accum(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+                   int64_t nmean, double *sum_out, int mem) {
+    if (ensure_init()) return -1;
+    if (check_frames("sp_welch_accum", nsig, nfft, hop, nframes)) return -1;
+    std::lock_guard<std::mutex> lk(g.mu);
+    const bool cplx = x_dtype == SP_DTYPE_C64;
+    const size_t esz = cplx ? 8 : 4;
+    const void *xd = x;
+    if (!mem) {
+        if (g.in0.ensure(esz * (size_t)nsig)) return -1;
+        HIPCHK(hipMemcpyAsync(g.in0.p, x, esz * (size_t)nsig, hipMemcpyHostToDevice, g.stream));
+        xd = g.in0.p;
+    }
+    if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean)) return -1;
+    if (sum_out) {
+        if (mem) HIPCHK(hipMemcpyAsync(sum_out, g_pend.sum_d, sizeof(double) * 2, hipMemcpyDeviceToDevice, g.stream));
+        else {
+            HIPCHK(hipMemcpyAsync(sum_out, g_pend.sum_d, sizeof(double) * 2, hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+        }
+    }
+    return 0;
+}
+
+int sp_welch_finish(const double *mean, int64_t frames_total, int sided, double scale, double *pxx_out, int mem) {
+    if (ensure_init()) return -1;
+    if (sided < 1 || sided > 3) return fail("sp_welch_finish: bad sided");
+    if (frames_total < 1) return fail("sp_welch_finish: frames_total must be positive");
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!g_pend.valid) return fail("sp_welch_finish: no pending sp_welch_accum");
+    const int nb = nbins_host(g_pend.nfft, sided);
+    double *out_d = pxx_out;
+    const double *mean_d = mean;
+    if (!mem) {
+        if (g.out0.ensure(sizeof(double) * (size_t)nb + 64)) return -1;
+        out_d = (double *)g.out0.p;
+        if (mean) {
+            double *md = out_d + nb + 2;
+            HIPCHK(hipMemcpyAsync(md, mean, sizeof(double) * 2, hipMemcpyHostToDevice, g.stream));
+            mean_d = md;
+        }
+    }
+    if (welch_finish_locked(mean_d, frames_total, sided, scale, out_d)) return -1;
     if (!mem) {
         HIPCHK(hipMemcpyAsync(pxx_out, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));

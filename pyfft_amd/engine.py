@@ -155,6 +155,47 @@ def welch_psd(x, win, hop, nframes, detrend=True, sided=SIDED_TWO, scale=1.0, me
     return out
 
 
+def welch_accum(x, win, hop, nframes, nmean=None):
+    """First half of the sharded Welch PSD (see include/spectral.h: sp_welch_accum): accumulates this shard's frames
+    against a local mean estimate.  Returns sum(x[0:nmean]) as a (2,) float64 (torch tensor on the device for device
+    input, numpy otherwise) for the cross-shard all-reduce."""
+    w = _win32(win)
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = _torch_samples(x)
+        nm = xs.numel() if nmean is None else int(nmean)
+        out = torch.empty(2, dtype=torch.float64, device=xs.device)
+        check(lib().sp_welch_accum(ptr(xs.data_ptr()), _tcode(xs), xs.numel(), ptr(w), w.size, int(hop), int(nframes), nm,
+                                   ptr(out.data_ptr()), 1))
+        return out
+    xs = _ffi.as_samples(x)
+    nm = xs.size if nmean is None else int(nmean)
+    out = np.empty(2, dtype=np.float64)
+    _ffi.init()
+    check(lib().sp_welch_accum(ptr(xs), _ffi.dtype_code(xs.dtype), xs.size, ptr(w), w.size, int(hop), int(nframes), nm,
+                               ptr(out), 0))
+    return out
+
+
+def welch_finish(nfft, mean, frames_total, sided=SIDED_TWO, scale=1.0, like=None):
+    """Second half: apply the (global) mean -- (2,) float64 [re, im], same kind of array welch_accum returned, or None
+    for the shard's own mean -- and return scale/frames_total * sum_{local frames} |X|^2 as float64 [nbins]."""
+    nb = nbins(nfft, sided)
+    if _is_torch(like) or _is_torch(mean):
+        dev = (mean if _is_torch(mean) else like).device
+        out = torch.empty(nb, dtype=torch.float64, device=dev)
+        mp = None
+        if mean is not None:
+            mean = mean.to(torch.float64).contiguous()
+            mp = ptr(mean.data_ptr())
+        check(lib().sp_welch_finish(mp, int(frames_total), sided, float(scale), ptr(out.data_ptr()), 1))
+        return out
+    out = np.empty(nb, dtype=np.float64)
+    m = None if mean is None else np.ascontiguousarray(mean, dtype=np.float64)
+    check(lib().sp_welch_finish(ptr(m), int(frames_total), sided, float(scale), ptr(out), 0))
+    return out
+
+
 # ------------------------------------------------------------------------------------------ A5
 def welch_csd(x, y, win, hop, nframes, detrend=True, sided=SIDED_ONE, scale=1.0):
     """Reference signal x[nsig] against channels y[nch, nsig] (channel-major).

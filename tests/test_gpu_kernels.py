@@ -186,6 +186,63 @@ def test_welch_carry_vs_generic_kernel(E):
         np.testing.assert_allclose(a, ref, rtol=2e-4, atol=1e-6 * ref.max())
 
 
+@pytest.mark.parametrize("nfft,hop,cplx", [(4096, 2048, True), (4096, 1024, True), (2048, 2048, False),
+                                           (1024, 512, False), (256, 64, True), (8192, 4096, True)])
+def test_welch_onepass_detrend(E, nfft, hop, cplx):
+    """global-mean detrend done in one pass (mean estimate + exact epilogue correction) == two-pass == oracle,
+    including a mean far larger than the signal, a drifting mean, and very few frames."""
+    import os
+    rng = np.random.default_rng(nfft + hop)
+    for nframes_extra, offset, drift in ((301, 0.3, 0.0), (57, 50.0, 0.0), (130, 2.0, 3.0), (0, 1.0, 0.0), (1, -4.0, 0.0)):
+        nsig = nfft + hop * nframes_extra + 11
+        k = np.arange(nsig) / nsig
+        x = rng.standard_normal(nsig) + offset + drift * k
+        if cplx:
+            x = x + 1j * (rng.standard_normal(nsig) - 0.5 * offset + 2 * drift * k ** 2)
+        x = x.astype(np.complex64 if cplx else np.float32)
+        M = (nsig - nfft) // hop + 1
+        win = O.windows("Hanning", nwins=nfft)
+        one = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+        assert "onepass" in E.profile_last_kernel()
+        os.environ["SP_WELCH_TWOPASS"] = "1"
+        try:
+            two = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+            assert "onepass" not in E.profile_last_kernel()
+        finally:
+            del os.environ["SP_WELCH_TWOPASS"]
+        ref = O.welch_psd_stream(x, win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+        np.testing.assert_allclose(two, ref, rtol=2e-4, atol=1e-6 * ref.max())
+        np.testing.assert_allclose(one, ref, rtol=2e-4, atol=1e-6 * ref.max())
+
+
+def test_welch_accum_finish_sharded(E):
+    """two shards of one stream, each accumulated separately and finished with the GLOBAL mean, add up to the
+    single-pass PSD of the whole stream (what pyfft_amd.dist does across GPUs)."""
+    rng = np.random.default_rng(99)
+    nfft, hop = 4096, 2048
+    nsig = nfft + hop * 200
+    x = (rng.standard_normal(nsig) + 1j * rng.standard_normal(nsig) + (1.5 - 0.7j)).astype(np.complex64)
+    x[: nsig // 2] += 2.0                     # the two halves have different means
+    M = (nsig - nfft) // hop + 1
+    win = O.windows("Hanning", nwins=nfft)
+    ref = O.welch_psd_stream(x, win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+    Ma = M // 2
+    xa = x[: (Ma - 1) * hop + nfft]           # shard A: frames [0, Ma) (+ halo)
+    xb = x[Ma * hop:]                         # shard B: frames [Ma, M)
+    own_a, own_b = Ma * hop, nsig - Ma * hop
+    sa = E.welch_accum(xa, win, hop, Ma, nmean=own_a)
+    np.testing.assert_allclose(sa[0] + 1j * sa[1], x[:own_a].astype(np.complex128).sum(), rtol=1e-6)
+    mean = None
+    # finish A needs the global mean: second shard's sum first (only one accumulation may be pending)
+    sb_direct = x[Ma * hop:].astype(np.complex128).sum()
+    gm = (sa[0] + 1j * sa[1] + sb_direct) / nsig
+    pa = E.welch_finish(nfft, np.array([gm.real, gm.imag]), M, sided=E.SIDED_TWO, scale=1.0)
+    sb = E.welch_accum(xb, win, hop, M - Ma, nmean=own_b)
+    np.testing.assert_allclose(sb[0] + 1j * sb[1], sb_direct, rtol=1e-6)
+    pb = E.welch_finish(nfft, np.array([gm.real, gm.imag]), M, sided=E.SIDED_TWO, scale=1.0)
+    np.testing.assert_allclose(pa + pb, ref, rtol=2e-4, atol=1e-6 * ref.max())
+
+
 def test_welch_errors(E):
     from pyfft_amd._ffi import SpectralError
     x = np.zeros(1000, dtype=np.float32)
