@@ -78,9 +78,10 @@ int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &
 }
 
 // ---- one-pass detrend epilogue ------------------------------------------------------------------
-int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, float *trend) {
-    if (cplx) hipLaunchKernelGGL((k_op_estimate<true>), dim3(1), dim3(1024), 0, c.stream, x, nsig, trend);
-    else hipLaunchKernelGGL((k_op_estimate<false>), dim3(1), dim3(1024), 0, c.stream, x, nsig, trend);
+int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, double *part, float *trend) {
+    if (cplx) hipLaunchKernelGGL((k_op_estimate<true>), dim3(SP_EST_RUNS), dim3(256), 0, c.stream, x, nsig, part);
+    else hipLaunchKernelGGL((k_op_estimate<false>), dim3(SP_EST_RUNS), dim3(256), 0, c.stream, x, nsig, part);
+    hipLaunchKernelGGL(k_op_estimate_fin, dim3(1), dim3(64), 0, c.stream, part, nsig, trend);
     return 0;
 }
 
@@ -90,7 +91,7 @@ int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, 
     const int N = xf.L, H = hop, r = N / H;
     hipLaunchKernelGGL(k_welch_finish, dim3((N + SP_FIN_BINS - 1) / SP_FIN_BINS), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
                        c.stream, partial, G, N, N, (int)SIDED_RAW, 1.0, st.A);
-    hipLaunchKernelGGL(k_op_reduce_s, dim3((H + 63) / 64), dim3(1024), 0, c.stream, spartial, G, H, st.Sl);
+    hipLaunchKernelGGL(k_op_reduce_s, dim3((H + 31) / 32), dim3(1024), 0, c.stream, spartial, G, H, st.Sl);
     if (cplx) hipLaunchKernelGGL((k_op_total<true>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot);
     else hipLaunchKernelGGL((k_op_total<false>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot);
     return 0;

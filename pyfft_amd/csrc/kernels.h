@@ -210,8 +210,10 @@ __global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, 
 // frame's last hop-block (time domain, SHIFT slots).  From those block sums the epilogue rebuilds
 // sum_g X_g[k] and the exact mean and applies  |X - dW|^2 = |X|^2 - 2Re(conj(dW) X) + |dW|^2.
 // ------------------------------------------------------------------------------------------
+// (no min-waves hint: capping at 168 VGPRs makes hipcc spill the window registers and reload them inside the
+//  frame loop behind vmcnt(0) waits, which also drains the prefetch loads -- measured 2x slower)
 template <int N, bool CPLX, int SHIFT, bool ONEPASS>
-__global__ __launch_bounds__(WgCfg<N>::WG, WgCfg<N>::WG == 256 ? 3 : 2) void k_welch_carry(
+__global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
     const void *__restrict__ x, const float *__restrict__ win, int64_t nframes, int64_t fpg,
     const float *__restrict__ trend, XfTables tb, float *__restrict__ partial, cf *__restrict__ spartial) {
     using X = XfPow2<N>;
@@ -288,26 +290,35 @@ struct OnePass {
     double *A, *Sl, *tot, *dlt;
 };
 
-// Sl[j] = sum over groups of spartial[g][j]  (complex, H entries); 64 entries x 16 slices per block
+// Sl[j] = sum over groups of spartial[g][j]  (complex, H entries); 32 entries x 32 slices per block
 static __global__ __launch_bounds__(1024) void k_op_reduce_s(const cf *__restrict__ sp, int64_t G, int H,
                                                               double *__restrict__ Sl) {
-    __shared__ double sh[2][16][64];
-    const int lane = threadIdx.x % 64, sl = threadIdx.x / 64;
-    const int j = blockIdx.x * 64 + lane;
-    double a = 0, b = 0;
-    if (j < H)
-        for (int64_t g = sl; g < G; g += 16) {
-            const cf v = sp[g * H + j];
-            a += v.x;
-            b += v.y;
+    __shared__ double sh[2][32][32];
+    const int lane = threadIdx.x % 32, sl = threadIdx.x / 32;
+    const int j = blockIdx.x * 32 + lane;
+    double a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+    if (j < H) {
+        int64_t g = sl;
+        for (; g + 96 < G; g += 128) {
+            const cf v0 = sp[g * H + j], v1 = sp[(g + 32) * H + j], v2 = sp[(g + 64) * H + j], v3 = sp[(g + 96) * H + j];
+            a0 += (double)v0.x + (double)v2.x;
+            b0 += (double)v0.y + (double)v2.y;
+            a1 += (double)v1.x + (double)v3.x;
+            b1 += (double)v1.y + (double)v3.y;
         }
-    sh[0][sl][lane] = a;
-    sh[1][sl][lane] = b;
+        for (; g < G; g += 32) {
+            const cf v = sp[g * H + j];
+            a0 += v.x;
+            b0 += v.y;
+        }
+    }
+    sh[0][sl][lane] = a0 + a1;
+    sh[1][sl][lane] = b0 + b1;
     __syncthreads();
     if (sl == 0 && j < H) {
         double ta = 0, tb = 0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < 32; ++q) {
             ta += sh[0][q][lane];
             tb += sh[1][q][lane];
         }
@@ -418,23 +429,26 @@ static __global__ void k_op_combine(const double *__restrict__ A, const cf *__re
     out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
 }
 
-// mean estimate from <= 65536 samples spread over the whole signal -> trend[4] = (mu0, 0 slope). one block.
+// mean estimate mu0: 64 contiguous runs of <= 1024 samples spread over the whole signal (robust to drift, and each
+// run is a coalesced read).  part[64][2] doubles; the finishing block writes trend[4] = (mu0, 0 slope).
+#define SP_EST_RUNS 64
+#define SP_EST_LEN 1024
 template <bool CPLX>
-static __global__ __launch_bounds__(1024) void k_op_estimate(const void *__restrict__ x, int64_t nsig,
-                                                              float *__restrict__ trend) {
-    __shared__ double sh[2][1024];
-    const int64_t cnt = nsig < 65536 ? nsig : 65536;
-    const int64_t stride = nsig / cnt;
+static __global__ __launch_bounds__(256) void k_op_estimate(const void *__restrict__ x, int64_t nsig,
+                                                             double *__restrict__ part) {
+    __shared__ double sh[2][256];
+    const int64_t len = nsig / SP_EST_RUNS < SP_EST_LEN ? nsig / SP_EST_RUNS : SP_EST_LEN;     // may be 0 for tiny signals
+    const int64_t start = (nsig / SP_EST_RUNS) * blockIdx.x;
     double a = 0, b = 0;
-    for (int64_t i = threadIdx.x; i < cnt; i += 1024) {
-        const cf v = load_sample(x, i * stride, CPLX);
+    for (int64_t i = threadIdx.x; i < len; i += 256) {
+        const cf v = load_sample(x, start + i, CPLX);
         a += v.x;
         b += v.y;
     }
     sh[0][threadIdx.x] = a;
     sh[1][threadIdx.x] = b;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
             sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
             sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
@@ -442,27 +456,52 @@ static __global__ __launch_bounds__(1024) void k_op_estimate(const void *__restr
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        trend[0] = (float)(sh[0][0] / (double)cnt);
-        trend[1] = (float)(sh[1][0] / (double)cnt);
+        part[2 * blockIdx.x] = sh[0][0];
+        part[2 * blockIdx.x + 1] = sh[1][0];
+    }
+}
+
+static __global__ void k_op_estimate_fin(const double *__restrict__ part, int64_t nsig, float *__restrict__ trend) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int64_t len = nsig / SP_EST_RUNS < SP_EST_LEN ? nsig / SP_EST_RUNS : SP_EST_LEN;
+        double a = 0, b = 0;
+        for (int r = 0; r < SP_EST_RUNS; ++r) {
+            a += part[2 * r];
+            b += part[2 * r + 1];
+        }
+        const double cnt = (double)(len * SP_EST_RUNS);
+        trend[0] = cnt > 0 ? (float)(a / cnt) : 0.f;
+        trend[1] = cnt > 0 ? (float)(b / cnt) : 0.f;
         trend[2] = 0.f;
         trend[3] = 0.f;
     }
 }
 
 // sum partial[G][L] over G in double, apply sidedness + scale -> out[nbins] (double).
-// block = 64 bins x 16 slices of the group range (1024 threads); deterministic order.
-#define SP_FIN_BINS 64
-#define SP_FIN_SLICES 16
+// block = 32 bins x 32 slices of the group range (1024 threads), 4 independent loads in flight per thread
+// (the reduction is latency-bound); deterministic order.
+#define SP_FIN_BINS 32
+#define SP_FIN_SLICES 32
 static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_welch_finish(const float *__restrict__ partial, int64_t G,
-                                                                              int L, int n, int sided, double scale,
-                                                                              double *__restrict__ out) {
+                                                                                     int L, int n, int sided, double scale,
+                                                                                     double *__restrict__ out) {
     __shared__ double sh[SP_FIN_SLICES][SP_FIN_BINS];
     const int lane = threadIdx.x % SP_FIN_BINS, sl = threadIdx.x / SP_FIN_BINS;
     const int k = blockIdx.x * SP_FIN_BINS + lane;
-    double s = 0.0;
-    if (k < n)
-        for (int64_t g = sl; g < G; g += SP_FIN_SLICES) s += (double)partial[g * L + k];
-    sh[sl][lane] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (k < n) {
+        int64_t g = sl;
+        for (; g + 3 * SP_FIN_SLICES < G; g += 4 * SP_FIN_SLICES) {
+            const float a0 = partial[g * L + k], a1 = partial[(g + SP_FIN_SLICES) * L + k];
+            const float a2 = partial[(g + 2 * SP_FIN_SLICES) * L + k], a3 = partial[(g + 3 * SP_FIN_SLICES) * L + k];
+            s0 += (double)a0;
+            s1 += (double)a1;
+            s2 += (double)a2;
+            s3 += (double)a3;
+        }
+        for (; g < G; g += SP_FIN_SLICES) s0 += (double)partial[g * L + k];
+    }
+    sh[sl][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl == 0 && k < n) {
         const int slot = bin_slot(k, n, sided);

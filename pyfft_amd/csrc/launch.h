@@ -54,7 +54,7 @@ bool welch_carry_eligible(const Xf &xf, int hop, bool lin);
 int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
                  bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, cf *spartial,
                  const char **kname);
-int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, float *trend);
+int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, double *part, float *trend);
 int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *partial, const cf *spartial,
                      int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st);
 int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, OnePass st,

@@ -348,7 +348,9 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     double *sum_d = st.dlt + 2;
     cf *cw = (cf *)((char *)g.onepass.p + sp_pad + st_pad);
     float *partial = (float *)g.work.p;
-    LAUNCHCHK(launch_op_estimate(lc(), xd, cplx, nsig, tb.f));
+    double *est = moments_scratch();
+    if (!est) return -1;
+    LAUNCHCHK(launch_op_estimate(lc(), xd, cplx, nsig, est, tb.f));
     {
         ProfScope ps;
         LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,

@@ -174,7 +174,7 @@ def test_welch_carry_vs_generic_kernel(E):
         M = (nsig - nfft) // hop + 1
         win = O.windows("Hanning", nwins=nfft)
         a = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
-        assert E.profile_last_kernel() == "k_welch_carry"
+        assert E.profile_last_kernel().startswith("k_welch_carry")
         os.environ["SP_WELCH_GENERIC"] = "1"
         try:
             b = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
