@@ -7,9 +7,10 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" = one pass of the hot path over one batch of synthetic input: every rank runs the fused Welch PSD
-(mean-detrend pre-pass + windowed overlapped FFT + |X|^2 + segment average) over its own 2^28-sample segment of
-the stream, device-resident, then the ranks' 4096-bin accumulators are summed with one RCCL all-reduce (the only
-exchange the path has).  Weak scaling: per-GPU work is fixed, value = all samples / max-over-ranks time.
+(global-mean detrend + window + overlapped FFT + |X|^2 + segment average, one pass over the samples) over its own
+2^28-sample segment of the stream, device-resident; at N>1 the shards' sample sums (2 doubles) and then their 4096-bin
+accumulators are summed with RCCL all-reduces (the only exchange the path has).  Weak scaling: per-GPU work is
+fixed, value = all samples / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.  Extra objects: roofline (dominant kernel k_welch, HIP events on the launch
 stream), cpu_baseline (the CPU oracle `welch_psd_stream`, 1 core, bounded sample; N=1 only).
@@ -28,8 +29,12 @@ sys.path.insert(0, ROOT)
 
 from pyfft_amd import engine as E          # noqa: E402
 from pyfft_amd.windows import windows      # noqa: E402
+from pyfft_amd.dist import shard_plan, welch_psd_sharded   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+# HBM bytes per launch of the dominant kernel from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB
+# units), profiles/r01_pmc_welch_carry.txt; measured at the default workload only -- null for any other size
+TRAFFIC_BYTES_PER_LAUNCH = None
 
 
 def synth_stream(n0, n, device, seed):
@@ -78,15 +83,11 @@ def main():
 
     nfft = args.nfft
     hop = nfft // 2
-    S = 1 << args.log2n                                  # samples owned by this rank
+    S = 1 << args.log2n                                  # samples per GPU (weak scaling)
     total = S * world                                    # whole stream
-    M_total = (total - nfft) // hop + 1
-    # frames whose first sample lies in this rank's segment; the last rank has no halo to read
-    f0 = rank * (S // hop)
-    f1 = M_total if rank == world - 1 else (rank + 1) * (S // hop)
-    M_local = f1 - f0
-    n_local = (M_local - 1) * hop + nfft                 # includes the (nfft-hop)-sample halo on inner ranks
-    x = synth_stream(rank * S, n_local, dev, seed=0x5EED2024 + rank)
+    plan = shard_plan(total, nfft, hop, world, rank)     # contiguous frame ranges + (nfft-hop)-sample halo
+    M_total, M_local, n_local = plan.frames_total, plan.frames, plan.nsamples
+    x = synth_stream(plan.first_sample, n_local, dev, seed=0x5EED2024 + rank)
 
     win = windows("Hanning", nwins=nfft, verbose=False)
     S2 = float(np.sum(win ** 2))
@@ -94,14 +95,12 @@ def main():
     scale = 1.0 / (Fs * S2)
 
     def step():
-        # global detrend (fft_analysis.py:2148): the stream mean.  At N>1 each rank removes its segment mean
-        # (the per-rank means are combined only in the accumulator; see DESIGN.md "multi-GPU")
-        p = E.welch_psd(x, win, hop, M_local, detrend=True, sided=E.SIDED_TWO, scale=scale)
-        if world > 1:
-            p = p * float(M_local)
-            dist.all_reduce(p)
-            p = p / float(M_total)
-        return p
+        # the whole hot path: global-mean detrend (fft_analysis.py:2148) + window + overlapped FFT + |X|^2 + segment
+        # average, in ONE pass over the samples; at N>1: all_reduce(2 doubles) for the stream mean, then
+        # all_reduce(nfft doubles) of the accumulator (pyfft_amd/dist.py)
+        if world == 1:
+            return E.welch_psd(x, win, hop, M_local, detrend=True, sided=E.SIDED_TWO, scale=scale)
+        return welch_psd_sharded(x, win, plan, scale=scale, sided=E.SIDED_TWO)
 
     E.profile_enable(True)
     for _ in range(args.warmup):
@@ -149,8 +148,10 @@ def main():
                    "samples_per_gpu": S, "frames_per_gpu": M_local, "parallelism": "segment-sharded x%d, "
                    "one RCCL all-reduce of the %d-bin accumulator" % (world, nfft)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "k_welch<%d,complex64>" % nfft,
-                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                     "kernel": "%s<%d,complex64>" % (E.profile_last_kernel(), nfft),
+                     "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "note": "fp32 VALU floor of this kernel is ~0.42 ms (DESIGN.md): it cannot reach the HBM line"},
     }
 
     if rank == 0 and world == 1 and args.cpu_log2n > 0:

@@ -1,0 +1,69 @@
+"""Segment-sharded Welch PSD across the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" =
+RCCL over xGMI).  The path shards by frames -- every rank owns a contiguous range of segments of one long stream
+plus a (nfft-hop)-sample halo -- and has exactly one real exchange: the averaged-PSD accumulator (nfft doubles,
+32 KiB at nfft=4096: latency-bound on any topology), preceded by a 2-double all-reduce of the sample sums so that the
+global-mean detrend (fft_analysis.py:2148) is the mean of the WHOLE stream, not of each shard.
+
+    plan = shard_plan(total_samples, nfft, hop, world, rank)
+    x_local = stream[plan.first_sample : plan.first_sample + plan.nsamples]          # device resident
+    pxx = welch_psd_sharded(x_local, win, plan, scale)                               # same on every rank
+"""
+from collections import namedtuple
+
+import numpy as np
+
+ShardPlan = namedtuple("ShardPlan", "rank world nfft hop frames_total first_frame frames first_sample nsamples "
+                                    "own_samples total_samples")
+
+
+def shard_plan(total_samples, nfft, hop, world, rank):
+    """Contiguous frame ranges, as even as possible.  Rank r owns the samples from its first frame's first sample up
+    to the next rank's first frame (the last rank: to the end of the stream); it additionally READS the halo that
+    its last frames extend into."""
+    total_samples, nfft, hop = int(total_samples), int(nfft), int(hop)
+    if total_samples < nfft:
+        raise ValueError("stream shorter than one segment")
+    M = (total_samples - nfft) // hop + 1
+    if world > M:
+        raise ValueError("more ranks (%d) than frames (%d)" % (world, M))
+    base, extra = divmod(M, world)
+    f0 = rank * base + min(rank, extra)
+    nf = base + (1 if rank < extra else 0)
+    first = f0 * hop
+    nsamp = (nf - 1) * hop + nfft
+    own_end = total_samples if rank == world - 1 else (f0 + nf) * hop
+    own_start = 0 if rank == 0 else first
+    return ShardPlan(rank, world, nfft, hop, M, f0, nf, first, nsamp if rank < world - 1 else total_samples - first,
+                     own_end - own_start, total_samples)
+
+
+def _device_backend():
+    from . import engine as E
+
+    def accum(x, win, hop, frames, nmean):
+        return E.welch_accum(x, win, hop, frames, nmean=nmean)
+
+    def finish(nfft, mean, frames_total, sided, scale, like):
+        return E.welch_finish(nfft, mean, frames_total, sided=sided, scale=scale, like=like)
+    return accum, finish
+
+
+def welch_psd_sharded(x_local, win, plan, scale=1.0, sided=2, group=None, backend=None):
+    """Welch PSD of the whole stream from this rank's shard (global-mean detrend).  Collectives: all_reduce(2 doubles),
+    all_reduce(nbins doubles).  `backend` = (accum, finish) callables; default: the HIP kernels.  With world == 1 no
+    collective is issued."""
+    import torch
+    import torch.distributed as dist
+    accum, finish = backend if backend is not None else _device_backend()
+    # each rank's own samples start at local index 0 (rank 0) / 0 too (its first frame starts at its first own sample)
+    s = accum(x_local, win, plan.hop, plan.frames, plan.own_samples)
+    is_t = isinstance(s, torch.Tensor)
+    st = s if is_t else torch.from_numpy(np.asarray(s, dtype=np.float64))
+    if plan.world > 1:
+        dist.all_reduce(st, group=group)
+    mean = st / float(plan.total_samples)
+    p = finish(plan.nfft, mean if is_t else mean.numpy(), plan.frames_total, sided, scale, x_local)
+    pt = p if isinstance(p, torch.Tensor) else torch.from_numpy(np.asarray(p, dtype=np.float64))
+    if plan.world > 1:
+        dist.all_reduce(pt, group=group)
+    return pt if isinstance(p, torch.Tensor) else pt.numpy()

@@ -243,6 +243,29 @@ def test_welch_accum_finish_sharded(E):
     np.testing.assert_allclose(pa + pb, ref, rtol=2e-4, atol=1e-6 * ref.max())
 
 
+def test_dist_world1_on_device(E):
+    """pyfft_amd.dist with device tensors and no process group (world = 1) == welch_psd"""
+    import torch
+    from pyfft_amd.dist import shard_plan, welch_psd_sharded
+    rng = np.random.default_rng(7)
+    nfft, hop = 4096, 2048
+    nsig = nfft + hop * 150 + 9
+    x = (rng.standard_normal(nsig) + 1j * rng.standard_normal(nsig) + (0.3 + 0.2j)).astype(np.complex64)
+    win = O.windows("Hanning", nwins=nfft)
+    plan = shard_plan(nsig, nfft, hop, 1, 0)
+    assert plan.nsamples == nsig and plan.own_samples == nsig
+    xt = torch.from_numpy(x).cuda()
+    p = welch_psd_sharded(xt, win, plan, scale=1.0)
+    assert p.is_cuda and p.dtype == torch.float64
+    ref = O.welch_psd_stream(x, win, nfft, hop, plan.frames_total, 1.0) * np.sum(win ** 2)
+    np.testing.assert_allclose(p.cpu().numpy(), ref, rtol=2e-4, atol=1e-6 * ref.max())
+    # device-tensor entry points of the other kernels
+    X = E.fft(xt[: 8 * nfft].reshape(8, nfft))
+    assert relerr(X.cpu().numpy(), np.fft.fft(x[: 8 * nfft].reshape(8, nfft).astype(np.complex128), axis=-1)) < 6e-6
+    h = E.hilbert_rows(xt.real[: 4 * 1024].reshape(4, 1024).contiguous(), 1024)
+    assert relerr(h.cpu().numpy(), O.hilbert(x.real[: 4 * 1024].reshape(4, 1024).astype(np.float64))) < 1e-4
+
+
 def test_welch_errors(E):
     from pyfft_amd._ffi import SpectralError
     x = np.zeros(1000, dtype=np.float32)
