@@ -34,7 +34,7 @@ from pyfft_amd.dist import shard_plan, welch_psd_sharded   # noqa: E402
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB
 # units), profiles/r01_pmc_welch_carry.txt; measured at the default workload only -- null for any other size
-TRAFFIC_BYTES_PER_LAUNCH = None
+TRAFFIC_BYTES_PER_LAUNCH = {(28, 4096): 1.08218e6 * 1024 * 2 + 65536 * 1024}
 
 
 def synth_stream(n0, n, device, seed):
@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=28, help="samples per GPU = 2^log2n")
     ap.add_argument("--nfft", type=int, default=4096)
-    ap.add_argument("--cpu-log2n", type=int, default=26, help="CPU-baseline sample = first 2^k samples (0 = skip)")
+    ap.add_argument("--cpu-log2n", type=int, default=28, help="CPU-baseline sample = first 2^k samples (0 = skip)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -148,7 +148,8 @@ def main():
                    "samples_per_gpu": S, "frames_per_gpu": M_local, "parallelism": "segment-sharded x%d, "
                    "one RCCL all-reduce of the %d-bin accumulator" % (world, nfft)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": TRAFFIC_BYTES_PER_LAUNCH,
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((args.log2n, nfft)) if world == 1 else None,
                      "kernel": "%s<%d,complex64>" % (E.profile_last_kernel(), nfft),
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "fp32 VALU floor of this kernel is ~0.42 ms (DESIGN.md): it cannot reach the HBM line"},
