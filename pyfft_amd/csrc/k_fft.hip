@@ -2,11 +2,11 @@
 #include "launch.h"
 namespace sp {
 
-int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf) {
+int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf, BigTw bt) {
     const int blocks = strided_blocks(xf.L, batch, c.ncu);
 #define M_(XT)                                                                                        \
     hipLaunchKernelGGL((k_fft_c2c<XT>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, batch, \
-                       inverse, xf.tb);
+                       inverse, xf.tb, bt);
     SP_DISPATCH_X(xf, M_)
 #undef M_
     return 0;
@@ -68,6 +68,50 @@ int launch_transpose(LaunchCtx c, const void *in, void *out, int64_t rows, int64
         hipLaunchKernelGGL((k_transpose<cf>), grid, dim3(32, 8), 0, c.stream, (const cf *)in, (cf *)out, rows, cols);
     else
         return -1;
+    return 0;
+}
+
+static int ew_blocks(int64_t n, int ncu) {
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)ncu * 16;
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+int launch_transpose_c(LaunchCtx c, const cf *in, cf *out, int64_t rows, int64_t cols, int conj, float scale) {
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+    hipLaunchKernelGGL(k_transpose_c, grid, dim3(32, 8), 0, c.stream, in, out, rows, cols, conj, scale);
+    return 0;
+}
+int launch_pack_real(LaunchCtx c, const float *x, int64_t n_in, const double *mean, int64_t L, cf *out) {
+    hipLaunchKernelGGL(k_pack_real, dim3(ew_blocks(L, c.ncu)), dim3(256), 0, c.stream, x, n_in, mean, L, out);
+    return 0;
+}
+int launch_cmul_vec(LaunchCtx c, const cf *a, const cf *b, int64_t n, int conj_out, cf *out) {
+    hipLaunchKernelGGL(k_cmul_vec, dim3(ew_blocks(n, c.ncu)), dim3(256), 0, c.stream, a, b, n, conj_out, out);
+    return 0;
+}
+int launch_blue_pre(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int64_t L, int conj_in, cf *out) {
+    hipLaunchKernelGGL(k_blue_pre, dim3(ew_blocks(L, c.ncu)), dim3(256), 0, c.stream, in, chirp, n, L, conj_in, out);
+    return 0;
+}
+int launch_blue_post(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int conj_out, float scale, cf *out) {
+    hipLaunchKernelGGL(k_blue_post, dim3(ew_blocks(n, c.ncu)), dim3(256), 0, c.stream, in, chirp, n, conj_out, scale, out);
+    return 0;
+}
+int launch_hilbert_mask(LaunchCtx c, cf *X, int64_t n) {
+    hipLaunchKernelGGL(k_hilbert_mask, dim3(ew_blocks(n, c.ncu)), dim3(256), 0, c.stream, X, n);
+    return 0;
+}
+int launch_xc_pack(LaunchCtx c, const float *x1, const float *x2, int64_t n, int64_t L, const double *mom, cf *z) {
+    hipLaunchKernelGGL(k_xc_pack, dim3(ew_blocks(L, c.ncu)), dim3(256), 0, c.stream, x1, x2, n, L, mom, z);
+    return 0;
+}
+int launch_xc_mid(LaunchCtx c, const cf *Z, int64_t L, cf *R) {
+    hipLaunchKernelGGL(k_xc_mid, dim3(ew_blocks(L, c.ncu)), dim3(256), 0, c.stream, Z, L, R);
+    return 0;
+}
+int launch_xc_out(LaunchCtx c, const cf *r, int64_t n, int64_t L, const double *mom, float *co) {
+    hipLaunchKernelGGL(k_xc_out, dim3(ew_blocks(2 * n - 1, c.ncu)), dim3(256), 0, c.stream, r, n, L, mom, co);
     return 0;
 }
 

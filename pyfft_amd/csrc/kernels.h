@@ -124,10 +124,18 @@ template <bool LIN> __device__ __forceinline__ cf detrended(cf a, const Trend &t
 
 // ------------------------------------------------------------------------------------------
 // A7  batched C2C FFT (fft_analysis.py:2096-2116).  inverse through conj(fft(conj(.)))/n.
+// BigTw (optional): after the transform, element (row b, column i) is multiplied by W_Ntot^{b*i} -- the twiddle
+// step of the multi-pass large FFT; W is looked up as hi[m >> lb] * lo[m & (2^lb-1)] (two 8192-entry tables keep
+// the phase accurate to float rounding for Ntot up to 2^26).
 // ------------------------------------------------------------------------------------------
+struct BigTw {
+    const cf *hi, *lo;
+    int lb;
+};
+
 template <class X>
 __global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in, cf *__restrict__ out, int64_t batch,
-                                                       int inverse, XfTables tb) {
+                                                       int inverse, XfTables tb, BigTw bt) {
     SP_KERNEL_PROLOGUE(X)
     const float sgn = inverse ? -1.f : 1.f;
     const float scl = inverse ? 1.f / (float)n : 1.f;
@@ -145,6 +153,13 @@ __global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in,
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, sgn * v[t].y);
         xf.fwd(v, lds, tid, n);
+        if (bt.lo != nullptr) {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t m = bl * (int64_t)(tid + C::T * t);
+                v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
+            }
+        }
         if (act) {
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
@@ -688,6 +703,95 @@ __global__ void k_transpose(const E *__restrict__ in, E *__restrict__ out, int64
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {
         const int64_t c = c0 + j, r = r0 + threadIdx.x;
         if (r < rows && c < cols) out[c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+// complex transpose with out = scale * (conj ? conj(in) : in): first / last pass of the large FFT
+static __global__ void k_transpose_c(const cf *__restrict__ in, cf *__restrict__ out, int64_t rows, int64_t cols,
+                                     int conj, float scale) {
+    __shared__ cf tile[32][33];
+    const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+    const float sg = conj ? -scale : scale;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int64_t r = r0 + j, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) {
+            const cf a = in[r * cols + c];
+            tile[j][threadIdx.x] = mk(scale * a.x, sg * a.y);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int64_t c = c0 + j, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) out[c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+// ---- elementwise pieces of the long (multi-kernel) paths ----------------------------------------
+// out[i] = i < n_in ? (x[i] - mean, 0) : 0   for i < L   (real -> zero-padded complex)
+static __global__ void k_pack_real(const float *__restrict__ x, int64_t n_in, const double *__restrict__ mean, int64_t L,
+                                   cf *__restrict__ out) {
+    const float m = mean ? (float)mean[0] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = i < n_in ? mk(x[i] - m, 0.f) : mk(0.f, 0.f);
+}
+// out[i] = a[i] * b[i] (optionally conj(a*b)), i < n
+static __global__ void k_cmul_vec(const cf *__restrict__ a, const cf *__restrict__ b, int64_t n, int conj_out,
+                                  cf *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cf p = cmul(a[i], b[i]);
+        out[i] = conj_out ? cconj(p) : p;
+    }
+}
+// Bluestein pre-multiply with zero padding: out[i] = i < n ? in[i]*chirp[i] : 0, i < L  (conj_in: use conj(in))
+static __global__ void k_blue_pre(const cf *__restrict__ in, const cf *__restrict__ chirp, int64_t n, int64_t L,
+                                  int conj_in, cf *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i < n) {
+            const cf a = in[i];
+            out[i] = cmul(conj_in ? cconj(a) : a, chirp[i]);
+        } else {
+            out[i] = mk(0.f, 0.f);
+        }
+    }
+}
+// Bluestein post-multiply: out[i] = scale * conj?(in[i] * chirp[i]),  i < n
+static __global__ void k_blue_post(const cf *__restrict__ in, const cf *__restrict__ chirp, int64_t n, int conj_out,
+                                   float scale, cf *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const cf p = cmul(in[i], chirp[i]);
+        out[i] = mk(scale * p.x, conj_out ? -scale * p.y : scale * p.y);
+    }
+}
+// analytic-signal mask (hilbert.py:63-64) in place: k=0 and k=nyq x1, 1..nyq-1 x2, > nyq x0
+static __global__ void k_hilbert_mask(cf *__restrict__ X, int64_t n) {
+    const int64_t nyq = (n & 1) ? (n + 1) / 2 : n / 2;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const float h = (k == 0 || k == nyq) ? 1.f : (k < nyq ? 2.f : 0.f);
+        X[k] = h * X[k];
+    }
+}
+// z = (x1-m1) + i (x2-m2), zero-padded to L;  mom[0]=m1, mom[1]=m2
+static __global__ void k_xc_pack(const float *__restrict__ x1, const float *__restrict__ x2, int64_t n, int64_t L,
+                                 const double *__restrict__ mom, cf *__restrict__ z) {
+    const float m1 = (float)mom[0], m2 = (float)mom[1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x)
+        z[i] = i < n ? mk(x1[i] - m1, x2[i] - m2) : mk(0.f, 0.f);
+}
+// R[k] = A conj(B) from Z = FFT(a + i b):  Im(Z[k] Z[L-k])/2 + i (|Z[k]|^2 - |Z[L-k]|^2)/4 ; stored CONJUGATED
+static __global__ void k_xc_mid(const cf *__restrict__ Z, int64_t L, cf *__restrict__ R) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < L; k += (int64_t)gridDim.x * blockDim.x) {
+        const cf z = Z[k], zm = Z[(L - k) & (L - 1)];
+        const cf zz = cmul(z, zm);
+        R[k] = mk(0.5f * zz.y, -0.25f * (cnorm(z) - cnorm(zm)));
+    }
+}
+// co[j], j < 2n-1, 'full' order from r = real(FFT(conj R))/L:  lag >= 0 -> r[lag], lag < 0 -> r[L+lag]; times mom[2]
+static __global__ void k_xc_out(const cf *__restrict__ r, int64_t n, int64_t L, const double *__restrict__ mom,
+                                float *__restrict__ co) {
+    const float nrm = (float)(mom[2] / (double)L);
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < 2 * n - 1; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lag = j - (n - 1);
+        co[j] = nrm * r[lag >= 0 ? lag : L + lag].x;
     }
 }
 

@@ -49,7 +49,18 @@ inline int strided_blocks(int L, int64_t items, int ncu) {
 }
 
 // every launcher returns 0 or -1 (unsupported L); kernel launch errors surface through hipGetLastError
-int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf);
+int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf,
+                   BigTw bt = BigTw{nullptr, nullptr, 0});
+// elementwise / transpose pieces of the long paths (k_fft.hip)
+int launch_transpose_c(LaunchCtx c, const cf *in, cf *out, int64_t rows, int64_t cols, int conj, float scale);
+int launch_pack_real(LaunchCtx c, const float *x, int64_t n_in, const double *mean, int64_t L, cf *out);
+int launch_cmul_vec(LaunchCtx c, const cf *a, const cf *b, int64_t n, int conj_out, cf *out);
+int launch_blue_pre(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int64_t L, int conj_in, cf *out);
+int launch_blue_post(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int conj_out, float scale, cf *out);
+int launch_hilbert_mask(LaunchCtx c, cf *X, int64_t n);
+int launch_xc_pack(LaunchCtx c, const float *x1, const float *x2, int64_t n, int64_t L, const double *mom, cf *z);
+int launch_xc_mid(LaunchCtx c, const cf *Z, int64_t L, cf *R);
+int launch_xc_out(LaunchCtx c, const cf *r, int64_t n, int64_t L, const double *mom, float *co);
 bool welch_carry_eligible(const Xf &xf, int hop, bool lin);
 int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
                  bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, cf *spartial,

@@ -18,6 +18,7 @@ using namespace sp;
 
 #define SP_VERSION 101
 #define SP_MAX_WG_FFT 8192
+#define SP_MAX_BIG_LOG2 26          /* longest multi-pass power-of-two transform: 2^26 points (512 MiB per buffer) */
 
 namespace {
 
@@ -77,6 +78,9 @@ struct Ctx {
     std::map<int64_t, cf *> twiddles;   // L -> exp(-2 pi i m/L)
     std::map<int64_t, BlueTab> blue;    // n -> Bluestein tables
     Scratch in0, in1, out0, work, small, trends, onepass;
+    Scratch bigA, bigB, bigT, blueA, blueB;   // long (multi-kernel) paths
+    std::map<int64_t, BigTw> bigtw;           // N -> two-level twiddle tables of the multi-pass FFT
+    std::map<int64_t, BlueTab> blue_big;      // n -> chirp[n], FFT_L(chirp*) (unscaled) for multi-pass Bluestein
     std::mutex mu;
     bool profile = false, prof_valid = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -311,6 +315,142 @@ bool env_flag(const char *name) {
 }
 
 
+// ---- transforms longer than one workgroup ---------------------------------------------------------
+bool wg_capable(int64_t n) {
+    if (n < 2) return false;
+    if (is_pow2(n)) return n <= SP_MAX_WG_FFT;
+    int64_t L = next_pow2(2 * n - 1);
+    return (L < 16 ? 16 : L) <= SP_MAX_WG_FFT;
+}
+
+int get_bigtw(int64_t N, BigTw *bt) {
+    auto it = g.bigtw.find(N);
+    if (it != g.bigtw.end()) {
+        *bt = it->second;
+        return 0;
+    }
+    int lg = 0;
+    while (((int64_t)1 << lg) < N) ++lg;
+    const int lb = lg < 13 ? lg : 13;
+    const int64_t nlo = (int64_t)1 << lb, nhi = N >> lb;
+    std::vector<cf> lo((size_t)nlo), hi((size_t)nhi);
+    for (int64_t j = 0; j < nlo; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)N;
+        lo[(size_t)j] = make_float2((float)cos(a), (float)sin(a));
+    }
+    for (int64_t j = 0; j < nhi; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)nhi;      // j * 2^lb / N
+        hi[(size_t)j] = make_float2((float)cos(a), (float)sin(a));
+    }
+    cf *dlo = nullptr, *dhi = nullptr;
+    HIPCHK(hipMalloc((void **)&dlo, sizeof(cf) * (size_t)nlo));
+    HIPCHK(hipMalloc((void **)&dhi, sizeof(cf) * (size_t)nhi));
+    HIPCHK(hipMemcpy(dlo, lo.data(), sizeof(cf) * (size_t)nlo, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dhi, hi.data(), sizeof(cf) * (size_t)nhi, hipMemcpyHostToDevice));
+    bt->hi = dhi;
+    bt->lo = dlo;
+    bt->lb = lb;
+    g.bigtw[N] = *bt;
+    return 0;
+}
+
+// N = 2^k, 2^14 <= N <= 2^26:  x viewed as [N1][N2]; transpose, N2 row FFTs of N1 (+ twiddle W_N^{n2 k1}),
+// transpose, N1 row FFTs of N2, transpose back to natural order.  5 passes over the data (80 B / point).
+int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse) {
+    int lg = 0;
+    while (((int64_t)1 << lg) < N) ++lg;
+    if (((int64_t)1 << lg) != N || lg > SP_MAX_BIG_LOG2) return fail("internal: dev_fft_big_pow2(%lld)", (long long)N);
+    const int64_t N1 = (int64_t)1 << ((lg + 1) / 2), N2 = N / N1;
+    Xf x1, x2;
+    if (get_xf(N1, &x1) || get_xf(N2, &x2)) return -1;
+    BigTw bt;
+    if (get_bigtw(N, &bt)) return -1;
+    if (g.bigT.ensure(sizeof(cf) * (size_t)N)) return -1;
+    cf *tmp = (cf *)g.bigT.p;
+    const float sc = inverse ? (float)(1.0 / (double)N) : 1.f;
+    if (in != out) {
+        LAUNCHCHK(launch_transpose_c(lc(), in, out, N1, N2, inverse, 1.f));        // out[n2][n1]
+        LAUNCHCHK(launch_fft_c2c(lc(), out, out, N2, 0, x1, bt));                   // A[n2][k1] W^{n2 k1}
+        LAUNCHCHK(launch_transpose_c(lc(), out, tmp, N2, N1, 0, 1.f));              // tmp[k1][n2]
+        LAUNCHCHK(launch_fft_c2c(lc(), tmp, tmp, N1, 0, x2));                       // B[k1][k2]
+        LAUNCHCHK(launch_transpose_c(lc(), tmp, out, N1, N2, inverse, sc));         // out[k2][k1]
+    } else {
+        if (g.blueB.ensure(sizeof(cf) * (size_t)N)) return -1;     // second temporary for the in-place form
+        cf *t2 = (cf *)g.blueB.p;
+        LAUNCHCHK(launch_transpose_c(lc(), in, tmp, N1, N2, inverse, 1.f));
+        LAUNCHCHK(launch_fft_c2c(lc(), tmp, tmp, N2, 0, x1, bt));
+        LAUNCHCHK(launch_transpose_c(lc(), tmp, t2, N2, N1, 0, 1.f));
+        LAUNCHCHK(launch_fft_c2c(lc(), t2, t2, N1, 0, x2));
+        LAUNCHCHK(launch_transpose_c(lc(), t2, out, N1, N2, inverse, sc));
+    }
+    return 0;
+}
+
+int get_blue_big(int64_t n, BlueTab *t) {
+    auto it = g.blue_big.find(n);
+    if (it != g.blue_big.end()) {
+        *t = it->second;
+        return 0;
+    }
+    const int64_t L = next_pow2(2 * n - 1);
+    std::vector<cf> ch((size_t)n), bw((size_t)L, make_float2(0.f, 0.f));
+    for (int64_t m = 0; m < n; ++m) {
+        const int64_t q = (int64_t)(((__int128)m * m) % (2 * n));
+        const double a = M_PI * (double)q / (double)n;
+        const float c = (float)cos(a), sn = (float)sin(a);
+        ch[(size_t)m] = make_float2(c, -sn);
+        bw[(size_t)m] = make_float2(c, sn);
+        if (m > 0) bw[(size_t)(L - m)] = make_float2(c, sn);
+    }
+    BlueTab nt;
+    nt.L = 0;
+    HIPCHK(hipMalloc((void **)&nt.chirp, sizeof(cf) * (size_t)n));
+    HIPCHK(hipMalloc((void **)&nt.bf, sizeof(cf) * (size_t)L));
+    HIPCHK(hipMemcpy(nt.chirp, ch.data(), sizeof(cf) * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(nt.bf, bw.data(), sizeof(cf) * (size_t)L, hipMemcpyHostToDevice));
+    if (dev_fft_big_pow2(nt.bf, nt.bf, L, 0)) return -1;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.blue_big[n] = nt;
+    *t = nt;
+    return 0;
+}
+
+// any length, device pointers.  in == out allowed.
+int dev_fft_any(const cf *in, cf *out, int64_t n, int64_t batch, int inverse) {
+    if (n == 1) {
+        if (in != out) HIPCHK(hipMemcpyAsync(out, in, sizeof(cf) * (size_t)batch, hipMemcpyDeviceToDevice, g.stream));
+        return 0;
+    }
+    if (wg_capable(n)) {
+        Xf xf;
+        if (get_xf(n, &xf)) return -1;
+        LAUNCHCHK(launch_fft_c2c(lc(), in, out, batch, inverse, xf));
+        return 0;
+    }
+    if (is_pow2(n)) {
+        if (n > ((int64_t)1 << SP_MAX_BIG_LOG2)) return fail("transform length %lld exceeds 2^%d", (long long)n, SP_MAX_BIG_LOG2);
+        for (int64_t b = 0; b < batch; ++b)
+            if (dev_fft_big_pow2(in + b * n, out + b * n, n, inverse)) return -1;
+        return 0;
+    }
+    const int64_t L = next_pow2(2 * n - 1);
+    if (L > ((int64_t)1 << SP_MAX_BIG_LOG2))
+        return fail("transform length %lld needs a 2^%d-point chirp-z; the limit is 2^%d", (long long)n, 0, SP_MAX_BIG_LOG2);
+    BlueTab bt;
+    if (get_blue_big(n, &bt)) return -1;
+    if (g.blueA.ensure(sizeof(cf) * (size_t)L)) return -1;
+    cf *A = (cf *)g.blueA.p;
+    for (int64_t b = 0; b < batch; ++b) {
+        LAUNCHCHK(launch_blue_pre(lc(), in + b * n, bt.chirp, n, L, inverse, A));
+        if (dev_fft_big_pow2(A, A, L, 0)) return -1;
+        LAUNCHCHK(launch_cmul_vec(lc(), A, bt.bf, L, 0, A));
+        if (dev_fft_big_pow2(A, A, L, 1)) return -1;
+        LAUNCHCHK(launch_blue_post(lc(), A, bt.chirp, n, inverse, inverse ? (float)(1.0 / (double)n) : 1.f, out + b * n));
+    }
+    return 0;
+}
+
+
 // ---- one-pass Welch: accumulate, then finish with a (possibly global) mean ------------------------
 int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
                        int64_t nmean) {
@@ -439,6 +579,21 @@ void sp_shutdown(void) {
     g.small.release();
     g.trends.release();
     g.onepass.release();
+    g.bigA.release();
+    g.bigB.release();
+    g.bigT.release();
+    g.blueA.release();
+    g.blueB.release();
+    for (auto &kv : g.bigtw) {
+        (void)hipFree((void *)kv.second.hi);
+        (void)hipFree((void *)kv.second.lo);
+    }
+    g.bigtw.clear();
+    for (auto &kv : g.blue_big) {
+        (void)hipFree(kv.second.chirp);
+        (void)hipFree(kv.second.bf);
+    }
+    g.blue_big.clear();
     g_pend.valid = false;
     tables_release();
     g.ready = false;
@@ -518,15 +673,6 @@ int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int directio
     if (direction != -1 && direction != 1) return fail("sp_fft_c2c: direction must be -1 or +1");
     if (batch == 0) return 0;
     std::lock_guard<std::mutex> lk(g.mu);
-    if (n == 1) {
-        if (in != out) {
-            if (mem) HIPCHK(hipMemcpyAsync(out, in, 8 * (size_t)batch, hipMemcpyDeviceToDevice, g.stream));
-            else memcpy(out, in, 8 * (size_t)batch);
-        }
-        return 0;
-    }
-    Xf xf;
-    if (get_xf(n, &xf)) return -1;
     const size_t bytes = sizeof(cf) * (size_t)n * (size_t)batch;
     const cf *din = (const cf *)in;
     cf *dout = (cf *)out;
@@ -536,7 +682,7 @@ int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int directio
         din = (const cf *)g.in0.p;
         dout = (cf *)g.in0.p;
     }
-    LAUNCHCHK(launch_fft_c2c(lc(), din, dout, batch, direction > 0, xf));
+    if (dev_fft_any(din, dout, n, batch, direction > 0)) return -1;
     if (!mem) {
         HIPCHK(hipMemcpyAsync(out, dout, bytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -762,8 +908,6 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
     if (ensure_init()) return -1;
     if (n_in < 1 || nfft < 2 || batch < 1 || x_ld < n_in) return fail("sp_hilbert: bad sizes");
     std::lock_guard<std::mutex> lk(g.mu);
-    Xf xf;
-    if (get_xf(nfft, &xf)) return -1;
     const float *xd = x;
     cf *od = (cf *)out;
     const size_t ibytes = sizeof(float) * (size_t)x_ld * (size_t)batch;
@@ -775,7 +919,21 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
         od = (cf *)g.out0.p;
     }
     const int64_t nuse = n_in < nfft ? n_in : nfft;
-    LAUNCHCHK(launch_hilbert(lc(), xd, nuse, x_ld, batch, xf, od));
+    if (wg_capable(nfft)) {
+        Xf xf;
+        if (get_xf(nfft, &xf)) return -1;
+        LAUNCHCHK(launch_hilbert(lc(), xd, nuse, x_ld, batch, xf, od));     // fwd + mask + inverse fused, one workgroup per row
+    } else {
+        // long rows: pack -> FFT -> mask -> inverse FFT, each a multi-pass transform
+        if (g.bigA.ensure(sizeof(cf) * (size_t)nfft)) return -1;
+        cf *A = (cf *)g.bigA.p;
+        for (int64_t b = 0; b < batch; ++b) {
+            LAUNCHCHK(launch_pack_real(lc(), xd + b * x_ld, nuse, nullptr, nfft, A));
+            if (dev_fft_any(A, A, nfft, 1, 0)) return -1;
+            LAUNCHCHK(launch_hilbert_mask(lc(), A, nfft));
+            if (dev_fft_any(A, od + b * nfft, nfft, 1, 1)) return -1;
+        }
+    }
     if (!mem) {
         HIPCHK(hipMemcpyAsync(out, od, obytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -787,7 +945,8 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
     if (ensure_init()) return -1;
     if (n < 1) return fail("sp_xcorr: n must be positive");
     const int64_t L = next_pow2(2 * n) < 2 ? 2 : next_pow2(2 * n);
-    if (L > SP_MAX_WG_FFT) return fail("sp_xcorr: n=%lld not supported yet (n <= %d)", (long long)n, SP_MAX_WG_FFT / 2);
+    if (L > ((int64_t)1 << SP_MAX_BIG_LOG2))
+        return fail("sp_xcorr: n=%lld needs a %lld-point transform; the limit is 2^%d", (long long)n, (long long)L, SP_MAX_BIG_LOG2);
     std::lock_guard<std::mutex> lk(g.mu);
     const float *a = x1, *b = x2;
     float *od = co_out;
@@ -807,9 +966,19 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
     LAUNCHCHK(launch_moments(lc(), a, false, n, 1, scr, tb.d, nullptr));
     LAUNCHCHK(launch_moments(lc(), b, false, n, 1, scr, tb.d + 8, nullptr));
     hipLaunchKernelGGL(k_xcorr_norm, dim3(1), dim3(64), 0, g.stream, tb.d, tb.d + 8, n, tb.d + 16);
-    Xf xf;
-    if (get_xf(L, &xf)) return -1;
-    LAUNCHCHK(launch_xcorr(lc(), a, b, n, tb.d + 16, xf, od));
+    if (L <= SP_MAX_WG_FFT) {
+        Xf xf;
+        if (get_xf(L, &xf)) return -1;
+        LAUNCHCHK(launch_xcorr(lc(), a, b, n, tb.d + 16, xf, od));          // one workgroup, everything in registers/LDS
+    } else {
+        if (g.bigA.ensure(sizeof(cf) * (size_t)L) || g.bigB.ensure(sizeof(cf) * (size_t)L)) return -1;
+        cf *A = (cf *)g.bigA.p, *B = (cf *)g.bigB.p;
+        LAUNCHCHK(launch_xc_pack(lc(), a, b, n, L, tb.d + 16, A));
+        if (dev_fft_big_pow2(A, B, L, 0)) return -1;
+        LAUNCHCHK(launch_xc_mid(lc(), B, L, A));                             // conj(A conj(B)) spectrum
+        if (dev_fft_big_pow2(A, B, L, 0)) return -1;                         // forward of the conjugate = L * real inverse
+        LAUNCHCHK(launch_xc_out(lc(), B, n, L, tb.d + 16, od));
+    }
     if (!mem) {
         HIPCHK(hipMemcpyAsync(co_out, od, obytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));

@@ -51,6 +51,23 @@ def test_fft_arbitrary_length(E, n):
     assert relerr(E.ifft(x), np.fft.ifft(x.astype(np.complex128), axis=-1)) <= 4e-6 * max(1.0, np.sqrt(np.log2(n)))
 
 
+@pytest.mark.parametrize("n", [1 << 14, 1 << 15, 1 << 17, 1 << 20, 10000, 50001, 100003, 131071])
+def test_fft_long(E, n):
+    """longer than one workgroup: multi-pass four-step FFT (powers of two) and chirp-z on top of it (other lengths)"""
+    rng = np.random.default_rng(n % 9973)
+    x = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(np.complex64)
+    ref = np.fft.fft(x.astype(np.complex128), axis=-1)
+    X = E.fft(x)
+    assert relerr(X, ref) <= 4e-6 * np.sqrt(np.log2(n))
+    assert relerr(E.ifft(X), x) <= 2e-5
+    assert relerr(E.ifft(x), np.fft.ifft(x.astype(np.complex128), axis=-1)) <= 4e-6 * np.sqrt(np.log2(n))
+    # a pure tone lands in one bin (phase accuracy of the long twiddles)
+    k0 = n // 3
+    tone = np.exp(2j * np.pi * k0 * np.arange(n) / n).astype(np.complex64)[None, :]
+    T = E.fft(tone)[0]
+    assert abs(T[k0] - n) < 2e-4 * n and np.max(np.abs(np.delete(T, k0))) < 2e-4 * n
+
+
 def test_fft_linearity_and_impulse(E):
     n = 4096
     x = np.zeros((3, n), dtype=np.complex64)
@@ -375,6 +392,19 @@ def test_hilbert_rows(E):
     assert np.max(np.abs(z6.T - g["z_2d_ax0"])) <= 1e-4 * np.abs(g["z_2d_ax0"]).max()
 
 
+def test_hilbert_long_rows(E):
+    """whole-signal analytic signal longer than one workgroup (transform length = the axis length)"""
+    rng = np.random.default_rng(31)
+    for n in (1 << 16, 30001, 100000):
+        u = rng.standard_normal((2, n))
+        z = E.hilbert_rows(u, n)
+        ref = O.hilbert(u)
+        assert np.max(np.abs(z - ref)) <= 1e-4 * np.abs(ref).max()
+    u = rng.standard_normal((1, 40000))
+    z = E.hilbert_rows(u, 1 << 16)                     # zero-padded transform length
+    assert np.max(np.abs(z[0] - O.hilbert(u[0], nfft=1 << 16))) <= 1e-4 * np.abs(u).max()
+
+
 # ---------------------------------------------------------------- A11 ccf
 def test_xcorr_golden(E):
     g = load_golden("ccf")
@@ -387,6 +417,21 @@ def test_xcorr_golden(E):
     a = E.xcorr_normalised(g["x1"], g["x1"])
     n = g["x1"].size
     assert abs(a[n - 1] - 1.0) < 1e-5 and np.max(np.abs(a - a[::-1])) < 1e-5
+
+
+@pytest.mark.parametrize("n", [5000, 70001, 1 << 18])
+def test_xcorr_long(E, n):
+    """more lags than one workgroup holds: the reference's O(N^2) np.correlate is infeasible here; the oracle's
+    FFT formulation (asserted equal to the direct form on the CPU) is the checker"""
+    rng = np.random.default_rng(n % 1000)
+    k = np.arange(n)
+    x1 = np.sin(0.01 * k) + rng.standard_normal(n) + 1.5
+    x2 = np.roll(x1, 37) + 0.5 * rng.standard_normal(n) - 0.5
+    co = E.xcorr_normalised(x1, x2)
+    tau, ref = O.ccf_fft(x1.astype(np.float32).astype(np.float64), x2.astype(np.float32).astype(np.float64), 1.0)
+    assert co.shape == ref.shape
+    assert np.max(np.abs(co - ref)) <= 1e-4 * np.abs(ref).max()
+    assert np.argmax(co) == np.argmax(ref)
 
 
 # ---------------------------------------------------------------- F1 FIR
