@@ -36,6 +36,7 @@ extern "C" {
 #define SP_SIDED_ONE 1 /* reference one-sided: bins [0,N/2), x2 on [1:-1] (Nyquist dropped; Q1) */
 #define SP_SIDED_TWO 2 /* two-sided, fftshift-ed                                               */
 #define SP_SIDED_RAW 3 /* two-sided, natural FFT order, no doubling                            */
+#define SP_SIDED_HALF 4 /* bins 0..nfft/2 (numpy rfft layout), no doubling                        */
 
 /* ---- context ------------------------------------------------------------------------ */
 int sp_init(int device_id);          /* select device, create context (idempotent)          */

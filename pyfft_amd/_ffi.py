@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libspectral.so")
 
 DTYPE_F32, DTYPE_C64 = 0, 1
-SIDED_ONE, SIDED_TWO, SIDED_RAW = 1, 2, 3
+SIDED_ONE, SIDED_TWO, SIDED_RAW, SIDED_HALF = 1, 2, 3, 4
 DETREND_CONST, DETREND_MEAN, DETREND_LINEAR = 0, 1, 2
 
 _lib = None

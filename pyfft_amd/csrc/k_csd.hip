@@ -30,4 +30,25 @@ int launch_csd_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf
     return 0;
 }
 
+int launch_csdm_transpose(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int64_t mc, int nb) {
+    dim3 grid((unsigned)((nb + 31) / 32), (unsigned)((mc + 31) / 32), (unsigned)nch);
+    hipLaunchKernelGGL(k_csdm_transpose, grid, dim3(32, 8), 0, c.stream, Xs, Xt, nch, mc, nb);
+    return 0;
+}
+
+int launch_csdm_gemm(LaunchCtx c, const cf *Xt, int nch, int64_t mc, int nb, double *G) {
+    const int nblk = (nch + SP_CM_B - 1) / SP_CM_B;
+    hipLaunchKernelGGL(k_csdm_gemm, dim3(nb, nblk * nblk), dim3(256), 0, c.stream, Xt, nch, mc, nblk, G);
+    return 0;
+}
+
+int launch_csdm_finish(LaunchCtx c, double *G, int nch, int nb, double scale) {
+    const int64_t total = (int64_t)nb * nch * nch;
+    int64_t b = (total + 255) / 256;
+    if (b > (int64_t)c.ncu * 16) b = (int64_t)c.ncu * 16;
+    hipLaunchKernelGGL(k_csdm_finish, dim3((int)b), dim3(256), 0, c.stream, G, nch, nb, scale);
+    hipLaunchKernelGGL(k_csdm_mirror, dim3((int)b), dim3(256), 0, c.stream, G, nch, nb);
+    return 0;
+}
+
 }   // namespace sp

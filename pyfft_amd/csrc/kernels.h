@@ -72,13 +72,14 @@ template <int L_> struct XfBlue {
     }
 };
 
-enum { SIDED_ONE = 1, SIDED_TWO = 2, SIDED_RAW = 3 };
+enum { SIDED_ONE = 1, SIDED_TWO = 2, SIDED_RAW = 3, SIDED_HALF = 4 };   // HALF: bins 0..n/2 (numpy rfft), no doubling
 
 // bin k of an n-point spectrum -> output slot for a sidedness (fft_analysis.py:2179-2193 / :402-428);
 // -1 when the bin is dropped.  nny = n/2 (even) or (n+1)/2 (odd)  (fft_analysis.py:2471-2484)
 __device__ __forceinline__ int nyq_of(int n) { return (n & 1) ? (n + 1) / 2 : n / 2; }
 __device__ __forceinline__ int bin_slot(int k, int n, int sided) {
     if (sided == SIDED_ONE) return k < nyq_of(n) ? k : -1;
+    if (sided == SIDED_HALF) return k <= n / 2 ? k : -1;
     if (sided == SIDED_TWO) {
         const int s = k + n / 2;
         return s >= n ? s - n : s;
@@ -90,7 +91,9 @@ __device__ __forceinline__ bool bin_doubled(int k, int n, int sided) {
     const int nny = nyq_of(n);
     return sided == SIDED_ONE && k >= 1 && (k <= nny - 2 || ((n & 1) && k == nny - 1));
 }
-__device__ __forceinline__ int nbins_of(int n, int sided) { return sided == SIDED_ONE ? nyq_of(n) : n; }
+__device__ __forceinline__ int nbins_of(int n, int sided) {
+    return sided == SIDED_ONE ? nyq_of(n) : (sided == SIDED_HALF ? n / 2 + 1 : n);
+}
 
 __device__ __forceinline__ cf load_sample(const void *x, int64_t i, bool cplx) {
     if (cplx) return reinterpret_cast<const cf *>(x)[i];
@@ -792,6 +795,112 @@ static __global__ void k_xc_out(const cf *__restrict__ r, int64_t n, int64_t L, 
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < 2 * n - 1; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t lag = j - (n - 1);
         co[j] = nrm * r[lag >= 0 ? lag : L + lag].x;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// cfg5  full cross-spectral-density matrix  G[k][i][j] = sum_g X_i[g,k] conj(X_j[g,k])
+// (generalises the reference x channel loop fft_analysis.py:387-393 / HeatPulse_Funcs.py:576-583).
+// Stage 1: k_stft per channel -> Xs[c][g][k].  Stage 2: k_csdm_transpose -> Xt[k][c][g] so that, for one bin, every
+// channel's frames are contiguous.  Stage 3: k_csdm_gemm, one workgroup per (bin, 64x64 channel block): frames are
+// staged through LDS 32 at a time, each thread owns a 4x4 tile of the block in registers (16 complex accumulators,
+// 64 FMA per 8 LDS loads -> VALU-bound), and adds its float sums into the float64 matrix in HBM once per chunk.
+// ------------------------------------------------------------------------------------------
+// Xs[c][g][k] (k fastest, nb per frame) -> Xt[k][c][g]  for g < mc
+static __global__ void k_csdm_transpose(const cf *__restrict__ Xs, cf *__restrict__ Xt, int nch, int64_t mc, int nb) {
+    __shared__ cf tile[32][33];
+    const int c = blockIdx.z;
+    const int64_t k0 = (int64_t)blockIdx.x * 32, g0 = (int64_t)blockIdx.y * 32;
+    const cf *src = Xs + (int64_t)c * mc * nb;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int64_t gg = g0 + j, k = k0 + threadIdx.x;
+        if (gg < mc && k < nb) tile[j][threadIdx.x] = src[gg * nb + k];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int64_t k = k0 + j, gg = g0 + threadIdx.x;
+        if (gg < mc && k < nb) Xt[(k * nch + c) * mc + gg] = tile[threadIdx.x][j];
+    }
+}
+
+#define SP_CM_B 64      // channel block
+#define SP_CM_F 32      // frames staged per step
+static __global__ __launch_bounds__(256) void k_csdm_gemm(const cf *__restrict__ Xt, int nch, int64_t mc, int nblk,
+                                                           double *__restrict__ G /*[nb][nch][nch][2]*/) {
+    __shared__ cf Ai[SP_CM_B][SP_CM_F + 1], Aj[SP_CM_B][SP_CM_F + 1];
+    const int k = blockIdx.x;
+    const int bi = blockIdx.y / nblk, bj = blockIdx.y % nblk;
+    if (bj < bi) return;                                   // Hermitian: the mirror block is filled at the end
+    const int ti = threadIdx.x / 16, tj = threadIdx.x % 16;
+    cf acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[u][v] = mk(0.f, 0.f);
+    const cf *base = Xt + (int64_t)k * nch * mc;
+    for (int64_t g0 = 0; g0 < mc; g0 += SP_CM_F) {
+        // stage 64 channels x 32 frames of both blocks (rows beyond nch / frames beyond mc are zero)
+        for (int e = threadIdx.x; e < SP_CM_B * SP_CM_F; e += 256) {
+            const int row = e / SP_CM_F, f = e % SP_CM_F;
+            const int64_t gg = g0 + f;
+            const int ci = bi * SP_CM_B + row, cj = bj * SP_CM_B + row;
+            Ai[row][f] = (ci < nch && gg < mc) ? base[(int64_t)ci * mc + gg] : mk(0.f, 0.f);
+            Aj[row][f] = (cj < nch && gg < mc) ? base[(int64_t)cj * mc + gg] : mk(0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int f = 0; f < SP_CM_F; ++f) {
+            cf a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a[u] = Ai[4 * ti + u][f];
+                b[u] = Aj[4 * tj + u][f];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    acc[u][v].x += a[u].x * b[v].x + a[u].y * b[v].y;       // a conj(b)
+                    acc[u][v].y += a[u].y * b[v].x - a[u].x * b[v].y;
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = bi * SP_CM_B + 4 * ti + u, j = bj * SP_CM_B + 4 * tj + v;
+            if (i < nch && j < nch) {
+                double *p = G + (((int64_t)k * nch + i) * nch + j) * 2;
+                p[0] += (double)acc[u][v].x;
+                p[1] += (double)acc[u][v].y;
+            }
+        }
+}
+
+// scale, and fill the blocks below the block diagonal from their Hermitian mirrors
+static __global__ void k_csdm_finish(double *__restrict__ G, int nch, int nb, double scale) {
+    const int64_t total = (int64_t)nb * nch * nch;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e % nch), i = (int)((e / nch) % nch);
+        const int64_t k = e / ((int64_t)nch * nch);
+        if (j / SP_CM_B >= i / SP_CM_B) {
+            G[2 * e] *= scale;
+            G[2 * e + 1] *= scale;
+        }
+    }
+}
+static __global__ void k_csdm_mirror(double *__restrict__ G, int nch, int nb) {
+    const int64_t total = (int64_t)nb * nch * nch;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e % nch), i = (int)((e / nch) % nch);
+        const int64_t k = e / ((int64_t)nch * nch);
+        if (j / SP_CM_B < i / SP_CM_B) {
+            const int64_t m = ((k * nch + j) * nch + i);
+            G[2 * e] = G[2 * m];
+            G[2 * e + 1] = -G[2 * m + 1];
+        }
     }
 }
 

@@ -79,6 +79,7 @@ struct Ctx {
     std::map<int64_t, BlueTab> blue;    // n -> Bluestein tables
     Scratch in0, in1, out0, work, small, trends, onepass;
     Scratch bigA, bigB, bigT, blueA, blueB;   // long (multi-kernel) paths
+    Scratch cmS, cmT, cmG;                    // CSD matrix: spectra, bin-major spectra, float64 accumulator
     std::map<int64_t, BigTw> bigtw;           // N -> two-level twiddle tables of the multi-pass FFT
     std::map<int64_t, BlueTab> blue_big;      // n -> chirp[n], FFT_L(chirp*) (unscaled) for multi-pass Bluestein
     std::mutex mu;
@@ -258,6 +259,17 @@ __global__ void k_set4(float *dst, float a, float b, float c, float d) {
     }
 }
 
+// dst[c] = trend of src[c] re-based to start at sample `offset`: (m + s*offset, s)
+__global__ void k_trend_shift(const float *src, float *dst, int count, double offset) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < count) {
+        dst[4 * c + 0] = (float)((double)src[4 * c + 0] + (double)src[4 * c + 2] * offset);
+        dst[4 * c + 1] = (float)((double)src[4 * c + 1] + (double)src[4 * c + 3] * offset);
+        dst[4 * c + 2] = src[4 * c + 2];
+        dst[4 * c + 3] = src[4 * c + 3];
+    }
+}
+
 __global__ void k_xcorr_norm(const double *mom1, const double *mom2, int64_t n, double *out /*[4]*/) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const double m1 = mom1[0], m2 = mom2[0];
@@ -307,7 +319,11 @@ int check_frames(const char *who, int64_t nsig, int nfft, int hop, int64_t nfram
     return 0;
 }
 
-int nbins_host(int n, int sided) { return sided == SP_SIDED_ONE ? ((n & 1) ? (n + 1) / 2 : n / 2) : n; }
+int nbins_host(int n, int sided) {
+    if (sided == SP_SIDED_ONE) return (n & 1) ? (n + 1) / 2 : n / 2;
+    if (sided == SP_SIDED_HALF) return n / 2 + 1;
+    return n;
+}
 
 bool env_flag(const char *name) {
     const char *v = getenv(name);
@@ -579,6 +595,9 @@ void sp_shutdown(void) {
     g.small.release();
     g.trends.release();
     g.onepass.release();
+    g.cmS.release();
+    g.cmT.release();
+    g.cmG.release();
     g.bigA.release();
     g.bigB.release();
     g.bigT.release();
@@ -847,9 +866,61 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
 
 int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft, int hop,
                   int64_t nframes, int detrend, double scale, double *g_out, int mem) {
-    (void)x; (void)nch; (void)nsig; (void)x_ld; (void)win; (void)nfft; (void)hop; (void)nframes; (void)detrend;
-    (void)scale; (void)g_out; (void)mem;
-    return fail("sp_csd_matrix: not implemented yet");
+    if (ensure_init()) return -1;
+    if (check_frames("sp_csd_matrix", nsig, nfft, hop, nframes)) return -1;
+    if (nch < 1 || x_ld < nsig) return fail("sp_csd_matrix: bad nch / x_ld");
+    if (detrend < 0 || detrend > 2) return fail("sp_csd_matrix: detrend must be 0, 1 or 2");
+    std::lock_guard<std::mutex> lk(g.mu);
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
+    const int nb = nfft / 2 + 1;
+    const float *xd = x;
+    if (!mem) {
+        const size_t ib = sizeof(float) * (size_t)x_ld * (size_t)nch;
+        if (g.in0.ensure(ib)) return -1;
+        HIPCHK(hipMemcpyAsync(g.in0.p, x, ib, hipMemcpyHostToDevice, g.stream));
+        xd = (const float *)g.in0.p;
+    }
+    void *win_d;
+    if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
+    TrendBuf tb;
+    if (get_trendbuf(2 * nch, &tb)) return -1;           // second half: trends re-based to the current frame chunk
+    for (int c = 0; c < nch; ++c)
+        if (set_trend(tb, c, xd + (size_t)x_ld * (size_t)c, false, nsig, detrend, 0, 0)) return -1;
+    const size_t gbytes = sizeof(double) * 2 * (size_t)nb * (size_t)nch * (size_t)nch;
+    double *G = g_out;
+    if (!mem) {
+        if (g.cmG.ensure(gbytes)) return -1;
+        G = (double *)g.cmG.p;
+    }
+    HIPCHK(hipMemsetAsync(G, 0, gbytes, g.stream));
+    // frames are processed in chunks so the two spectra buffers stay <= 2 GiB each (and float sums stay short)
+    int64_t mc = ((int64_t)1 << 28) / ((int64_t)nch * nb);
+    if (mc > 8192) mc = 8192;
+    if (mc < 32) mc = 32;
+    mc &= ~(int64_t)31;
+    if (mc > nframes) mc = nframes;
+    const size_t sbytes = sizeof(cf) * (size_t)nch * (size_t)mc * (size_t)nb;
+    if (g.cmS.ensure(sbytes) || g.cmT.ensure(sbytes)) return -1;
+    cf *Xs = (cf *)g.cmS.p, *Xt = (cf *)g.cmT.p;
+    for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
+        const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
+        const RunPart rp = run_partition(xf.L, m, g.ncu, 2);
+        hipLaunchKernelGGL(k_trend_shift, dim3((nch + 63) / 64), dim3(64), 0, g.stream, tb.f, tb.f + 4 * nch, nch,
+                           (double)f0 * (double)hop);
+        for (int c = 0; c < nch; ++c)
+            LAUNCHCHK(launch_stft(lc(), xd + (size_t)x_ld * (size_t)c + (size_t)f0 * (size_t)hop, false, (const float *)win_d,
+                                  hop, m, tb.f + 4 * (nch + c), detrend == 2, xf, rp, SP_SIDED_HALF, 1.f, 0,
+                                  Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
+        LAUNCHCHK(launch_csdm_transpose(lc(), Xs, Xt, nch, m, nb));
+        LAUNCHCHK(launch_csdm_gemm(lc(), Xt, nch, m, nb, G));
+    }
+    LAUNCHCHK(launch_csdm_finish(lc(), G, nch, nb, scale / (double)nframes));
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(g_out, G, gbytes, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
 }
 
 int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,

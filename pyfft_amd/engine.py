@@ -11,7 +11,7 @@ There is no CPU implementation behind these functions.
 import numpy as np
 
 from . import _ffi
-from ._ffi import SIDED_ONE, SIDED_TWO, SIDED_RAW, check, lib, ptr
+from ._ffi import SIDED_ONE, SIDED_TWO, SIDED_RAW, SIDED_HALF, check, lib, ptr
 
 try:                                    # torch is optional plumbing (device memory + streams)
     import torch
@@ -49,6 +49,8 @@ def nbins(nfft, sided):
     """Nnyquist bins for the reference's one-sided crop (fft_analysis.py:2471-2484), else nfft."""
     if sided == SIDED_ONE:
         return (nfft + 1) // 2 if nfft % 2 else nfft // 2
+    if sided == SIDED_HALF:
+        return nfft // 2 + 1
     return nfft
 
 
@@ -234,6 +236,29 @@ def welch_csd(x, y, win, hop, nframes, detrend=True, sided=SIDED_ONE, scale=1.0)
                              int(nframes), _detrend_args(detrend, None)[0], None, None, sided, float(scale), ptr(pxx),
                              ptr(pyy), ptr(pxy), 0))
     return pxx, pyy, pxy
+
+
+def csd_matrix(x, win, hop, nframes, detrend=True, scale=1.0):
+    """Full cross-spectral-density matrix of real channels x[nch, nsig]:
+    G[k, i, j] = scale/nframes * sum_g X_i[g,k] conj(X_j[g,k]),  k = 0..nfft/2 (rfft bins, no doubling), complex128."""
+    w = _win32(win)
+    nfft = w.size
+    nb = nfft // 2 + 1
+    want = _detrend_args(detrend, None)[0]
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = x.to(torch.float32).contiguous()
+        nch, ld = xs.shape
+        out = torch.empty((nb, nch, nch), dtype=torch.complex128, device=xs.device)
+        check(lib().sp_csd_matrix(ptr(xs.data_ptr()), nch, ld, ld, ptr(w), nfft, int(hop), int(nframes), want,
+                                  float(scale), ptr(out.data_ptr()), 1))
+        return out
+    xs = np.ascontiguousarray(x, dtype=np.float32)
+    nch, ld = xs.shape
+    out = np.empty((nb, nch, nch), dtype=np.complex128)
+    _ffi.init()
+    check(lib().sp_csd_matrix(ptr(xs), nch, ld, ld, ptr(w), nfft, int(hop), int(nframes), want, float(scale), ptr(out), 0))
+    return out
 
 
 # ------------------------------------------------------------------------------------------ A8/A9

@@ -329,6 +329,29 @@ def test_welch_csd_multichannel_twosided(E):
         np.testing.assert_allclose(pxy[c], rxy, rtol=2e-4, atol=2e-6 * np.abs(rxy).max())
 
 
+@pytest.mark.parametrize("nch,nfft,hop,nsig", [(5, 256, 128, 6000), (64, 1024, 512, 20000), (70, 512, 256, 9000),
+                                                (3, 1000, 300, 7000)])
+def test_csd_matrix(E, nch, nfft, hop, nsig):
+    """cfg5 shape (reduced): common component with per-channel gain/delay + independent noise; full nch x nch matrix,
+    including more than one 64-channel block, a ragged last frame chunk and a non power-of-two segment"""
+    rng = np.random.default_rng(nch * nfft)
+    k = np.arange(nsig)
+    common = np.sin(0.13 * k) + 0.5 * rng.standard_normal(nsig)
+    x = np.stack([(0.3 + 0.05 * c) * np.roll(common, c % 7) + rng.standard_normal(nsig) + 0.1 * c
+                  for c in range(nch)]).astype(np.float32)
+    M = (nsig - nfft) // hop + 1
+    win = O.windows("Hanning", nwins=nfft)
+    G = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+    ref = O.csd_matrix(x.astype(np.float64), win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+    assert G.shape == ref.shape == (nfft // 2 + 1, nch, nch)
+    assert np.max(np.abs(G - ref)) <= 2e-4 * np.abs(ref).max()
+    # Hermitian in (i, j), real non-negative diagonal
+    assert np.max(np.abs(G - np.conj(np.swapaxes(G, 1, 2)))) <= 1e-12 * np.abs(G).max()
+    # diagonal == Welch PSD of each channel (rfft layout)
+    p0 = E.welch_psd(x[0], win, hop, M, detrend=True, sided=E.SIDED_RAW, scale=1.0)[: nfft // 2 + 1]
+    np.testing.assert_allclose(G[:, 0, 0].real, p0, rtol=1e-4, atol=1e-6 * p0.max())
+
+
 # ---------------------------------------------------------------- A8/A9 STFT / specgram
 def test_stft_golden_f32(E):
     g = load_golden("stft_f32_n2048_ov75")
