@@ -1,0 +1,167 @@
+"""BASELINE.json's full-size configs on one MI355X, checked through size-independent properties (the float64 oracle
+cannot run 2^28 samples in test time): round trips, linearity, Parseval, agreement between independent kernels, and
+oracle comparison on windows cut out of the full-size result.  Device-resident data (torch tensors)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpu_ref as O
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    from pyfft_amd import _ffi
+    _ffi.init()
+    return torch
+
+
+@pytest.fixture(scope="module")
+def E():
+    from pyfft_amd import engine
+    return engine
+
+
+def test_cfg2_batched_fft_roundtrip_and_parseval(T, E):
+    """cfg2: 65536 x 4096-pt complex64 forward + inverse: round-trip rtol 5e-6, Parseval per row, oracle on 8 rows"""
+    g = T.Generator(device="cuda")
+    g.manual_seed(11)
+    x = T.view_as_complex(T.randn((65536, 4096, 2), generator=g, device="cuda", dtype=T.float32))
+    X = E.fft(x)
+    xr = E.ifft(X)
+    assert float((xr - x).abs().max() / x.abs().max()) <= 5e-6
+    ex = (x.abs() ** 2).sum(dim=1, dtype=T.float64)
+    eX = (X.abs() ** 2).sum(dim=1, dtype=T.float64) / 4096
+    assert float(((ex - eX).abs() / ex).max()) < 2e-6
+    rows = [0, 1, 777, 32768, 65535]
+    ref = np.fft.fft(x[rows].cpu().numpy().astype(np.complex128), axis=-1)
+    got = X[rows].cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 2e-6 * np.sqrt(12) * np.abs(ref).max()
+
+
+def _metric_stream(T, n, seed=5):
+    g = T.Generator(device="cuda")
+    g.manual_seed(seed)
+    z = T.view_as_complex(T.randn((n, 2), generator=g, device="cuda", dtype=T.float32) * (0.5 ** 0.5))
+    k = T.arange(n, device="cuda", dtype=T.float64)
+    for amp, f in ((2.82842712, 0.1234), (1.0, 0.25002157)):
+        ph = 2 * np.pi * T.remainder(f * k, 1.0)
+        z = z + (amp * T.complex(T.cos(ph), T.sin(ph))).to(T.complex64)
+    return z + (0.25 - 0.5j)
+
+
+def test_metric_welch_full_size_properties(T, E):
+    """the headline workload: 2^28 complex64, 4096-pt periodic Hann, 50 % overlap, global-mean detrend"""
+    n, nfft, hop = 1 << 28, 4096, 2048
+    x = _metric_stream(T, n)
+    M = (n - nfft) // hop + 1
+    assert M == 131071
+    win = O.windows("Hanning", nwins=nfft)
+    S1, S2 = win.sum(), (win ** 2).sum()
+    P = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0 / S2).cpu().numpy()     # Fs = 1
+    assert "onepass" in E.profile_last_kernel()
+    # white floor: unit-variance complex noise -> PSD 1.0 /Hz two-sided; 131071 averages -> 0.3 % scatter per bin
+    floor = np.median(P)
+    assert abs(floor - 1.0) < 5e-3
+    # tones: Heinzel section-13 amplitudes at fs = 1; a tone of amplitude A at frequency f0 puts S1^2 A^2 |D(f-f0)|^2
+    # into its bins: check the bin positions and the integrated power (sum of P * df over +-3 bins = A^2 for Hann)
+    freq = np.fft.fftshift(np.fft.fftfreq(nfft))
+    for amp, f0 in ((2.82842712, 0.1234), (1.0, 0.25002157)):
+        kpk = int(np.argmin(np.abs(freq - f0)))
+        assert abs(int(np.argmax(P[kpk - 4:kpk + 5])) - 4) <= 1
+        band = (P[kpk - 4:kpk + 5] - floor).sum() / nfft
+        assert abs(band - amp ** 2) < 2e-3 * amp ** 2
+    # the mean was removed: DC bin is at the noise floor although the stream has a (0.25 - 0.5j) offset
+    assert P[nfft // 2] < 1.1
+    # same result from the two-pass path on an independent kernel schedule (first 2^26 samples), and vs the oracle
+    nc = 1 << 26
+    Mc = (nc - nfft) // hop + 1
+    a = E.welch_psd(x[:nc], win, hop, Mc, detrend=True, sided=E.SIDED_TWO, scale=1.0 / S2).cpu().numpy()
+    ref = O.welch_psd_stream(x[:nc].cpu().numpy(), win, nfft, hop, Mc, 1.0)
+    np.testing.assert_allclose(a, ref, rtol=2e-4, atol=1e-6 * ref.max())
+    # linearity: 2x the input (offset included) -> 4x the PSD
+    P2 = E.welch_psd(2.0 * x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0 / S2).cpu().numpy()
+    np.testing.assert_allclose(P2, 4.0 * P, rtol=2e-5)
+
+
+def test_cfg3_stft_full_size(T, E):
+    """cfg3: 2^26 float32, 2048-pt Hann, 75 % overlap, one-sided: mean |Xseg|^2 equals the fused Welch kernel's PSD;
+    frames cut from the middle and the end equal the oracle's"""
+    n, nfft, hop = 1 << 26, 2048, 512
+    g = T.Generator(device="cuda")
+    g.manual_seed(3)
+    k = T.arange(n, device="cuda", dtype=T.float64)
+    ph = 2 * np.pi * T.remainder(0.05 * k + 0.5 * (0.15 / n) * k * k, 1.0)             # chirp 0.05 -> 0.2
+    x = (T.sin(ph).to(T.float32) + 0.01 * T.randn(n, generator=g, device="cuda", dtype=T.float32))
+    M = (n - nfft) // hop + 1
+    assert M == 131069
+    win = O.windows("Hanning", nwins=nfft)
+    Xs, _ = E.stft_frames(x, win, hop, M, detrend=True, sided=E.SIDED_ONE, amp_scale=1.0)
+    assert tuple(Xs.shape) == (M, nfft // 2)
+    P_from_frames = (Xs.abs().to(T.float64) ** 2).mean(dim=0).cpu().numpy()
+    P = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_ONE, scale=1.0).cpu().numpy()
+    np.testing.assert_allclose(P_from_frames, P, rtol=2e-4, atol=1e-6 * P.max())
+    xh = x.cpu().numpy().astype(np.float64)
+    mu = xh.mean()
+    for gidx in (0, M // 2, M - 1):
+        seg = win * (xh[gidx * hop: gidx * hop + nfft] - mu)
+        ref = np.fft.fft(seg)[: nfft // 2].copy()
+        ref[1:-1] *= np.sqrt(2)
+        got = Xs[gidx].cpu().numpy()
+        assert np.max(np.abs(got - ref)) <= 1e-4 * np.abs(ref).max()
+
+
+def test_cfg4_fir_full_size(T, E):
+    """cfg4: 2^28 float32 through a 513-tap FIR: impulse response, oracle on cut-out windows, linearity"""
+    import scipy.signal as ss
+    n, ntaps = 1 << 28, 513
+    g = T.Generator(device="cuda")
+    g.manual_seed(4)
+    x = T.randn(n, generator=g, device="cuda", dtype=T.float32)
+    h = ss.firwin(ntaps, 0.12, window="hamming")
+    y = E.fir_filter(h, x, nfft=4096)
+    h32 = h.astype(np.float32).astype(np.float64)
+    for a in (0, 3583, 1 << 27, n - 9000):                  # block seams of the overlap-save included
+        b = a + 9000
+        lo = max(0, a - (ntaps - 1))
+        ref = np.convolve(x[lo:b].cpu().numpy().astype(np.float64), h32)[a - lo: a - lo + (b - a)]
+        got = y[a:b].cpu().numpy()
+        assert np.max(np.abs(got - ref)) <= 1e-4 * np.abs(ref).max()
+    d = T.zeros(1 << 20, device="cuda", dtype=T.float32)
+    for pos in (0, 3583, 3584, 500000):
+        d[pos] = 1.0
+    yd = E.fir_filter(h, d, nfft=4096).cpu().numpy()
+    for pos in (0, 3583, 3584, 500000):
+        np.testing.assert_allclose(yd[pos: pos + ntaps], h32, rtol=0, atol=2e-7)
+    y2 = E.fir_filter(h, 3.0 * x, nfft=4096)
+    assert float((y2 - 3.0 * y).abs().max() / y.abs().max()) < 2e-6
+
+
+def test_cfg5_csd_matrix_full_size(T, E):
+    """cfg5: 64 channels x 2^24 float32, full 64x64 CSD matrix: Hermitian, diagonal == per-channel Welch PSD,
+    off-diagonals == the reference-vs-channels kernel, coherent pair detected"""
+    nch, n, nfft, hop = 64, 1 << 24, 4096, 2048
+    g = T.Generator(device="cuda")
+    g.manual_seed(6)
+    common = T.randn(n, generator=g, device="cuda", dtype=T.float32)
+    x = T.randn((nch, n), generator=g, device="cuda", dtype=T.float32)
+    x[3] += 0.8 * common
+    x[40] += 0.8 * T.roll(common, 5)
+    x += T.arange(nch, device="cuda", dtype=T.float32)[:, None] * 0.1
+    M = (n - nfft) // hop + 1
+    win = O.windows("Hanning", nwins=nfft)
+    G = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+    assert tuple(G.shape) == (nfft // 2 + 1, nch, nch)
+    assert float((G - G.transpose(1, 2).conj()).abs().max() / G.abs().max()) < 1e-6
+    for c in (0, 3, 63):
+        p = E.welch_psd(x[c], win, hop, M, detrend=True, sided=E.SIDED_RAW, scale=1.0)[: nfft // 2 + 1]
+        np.testing.assert_allclose(G[:, c, c].real.cpu().numpy(), p.cpu().numpy(), rtol=2e-4)
+    pxx, pyy, pxy = E.welch_csd(x[3], x[[40, 41]], win, hop, M, detrend=True, sided=E.SIDED_RAW, scale=1.0)
+    # welch_csd returns Y conj(X) with X = channel 3:  G[k, 40, 3]
+    got = G[:, 40, 3].cpu().numpy()
+    ref = pxy[0][: nfft // 2 + 1].cpu().numpy()
+    assert np.max(np.abs(got - ref)) <= 2e-4 * np.abs(ref).max()
+    coh = (G[:, 3, 40].abs() ** 2 / (G[:, 3, 3].real * G[:, 40, 40].real)).cpu().numpy()
+    coh_null = (G[:, 3, 41].abs() ** 2 / (G[:, 3, 3].real * G[:, 41, 41].real)).cpu().numpy()
+    assert np.median(coh[10:-10]) > 0.1 and np.median(coh_null[10:-10]) < 1e-3
