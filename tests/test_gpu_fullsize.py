@@ -132,8 +132,12 @@ def test_cfg4_fir_full_size(T, E):
     for pos in (0, 3583, 3584, 500000):
         d[pos] = 1.0
     yd = E.fir_filter(h, d, nfft=4096).cpu().numpy()
-    for pos in (0, 3583, 3584, 500000):
-        np.testing.assert_allclose(yd[pos: pos + ntaps], h32, rtol=0, atol=2e-7)
+    np.testing.assert_allclose(yd[:ntaps], h32, rtol=0, atol=2e-7)                       # impulse at 0
+    np.testing.assert_allclose(yd[500000: 500000 + ntaps], h32, rtol=0, atol=2e-7)       # impulse inside a block
+    both = np.zeros(ntaps + 1)                                                           # impulses on a block seam
+    both[:ntaps] += h32
+    both[1:] += h32
+    np.testing.assert_allclose(yd[3583: 3583 + ntaps + 1], both, rtol=0, atol=3e-7)
     y2 = E.fir_filter(h, 3.0 * x, nfft=4096)
     assert float((y2 - 3.0 * y).abs().max() / y.abs().max()) < 2e-6
 
