@@ -9,9 +9,9 @@
 //
 // Passes: radix-16 as many times as they fit, then one radix-{2,4,8} remainder.  Between
 // passes the group exchanges through LDS (Stockham: scattered write, unit-stride read):
-//   - the first exchange (stride-16 scatter) uses a [s][q] image with row pitch T+2 complex
-//     so that both the 16-lane ds_write_b64 groups and the 32-lane ds_read_b64 groups are
-//     bank-conflict free (bank = dword mod 32 for writes, mod 64 for b64 reads);
+//   - the first exchange (stride-16 scatter) uses a [s][q] image with row pitch T+1 complex
+//     so that both the 16-lane ds_write_b64 groups and the 16-lane ds_read2_b64 groups (what
+//     hipcc emits for the unit-stride reads) are bank-conflict free (bank = dword mod 32);
 //   - later exchanges are conflict free in the plain linear image.
 // Twiddles W_N^m come from a per-N global table (float, rounded from double on the host) and
 // are held in registers across frames.
@@ -121,7 +121,11 @@ template <int N> struct FftPlan {
     // per-thread twiddle count: passes p>=1, (R/r) butterflies x (r-1) factors
     static constexpr int ntw_before(int p) { int c = 0; for (int i = 1; i < p; ++i) c += (R / radix(i)) * (radix(i) - 1); return c; }
     static constexpr int NTW = ntw_before(NP);
-    static constexpr int PITCH1 = T + 2;                       // first-exchange row pitch (complex)
+    // first-exchange row pitch (complex).  hipcc merges the unit-stride reads into ds_read2_b64 (16-lane groups,
+    // bank = dword mod 32): lane stride must be == 2 dwords mod 32 -> pitch == 1 mod 16.  (T+2 would suit plain
+    // ds_read_b64 -- 32-lane groups, 64 banks -- and costs a 2-way conflict on every read2: measured 256 LDS
+    // conflict cycles per 4096-point frame.)
+    static constexpr int PITCH1 = T + 1;
     static constexpr int LDS_ELEMS = NP > 1 ? (R * PITCH1 > N ? R * PITCH1 : N) : 0;
 };
 

@@ -18,10 +18,10 @@ static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int
 #define CARRY_(S)                                                                                     \
     case S:                                                                                           \
         if (spartial)                                                                                 \
-            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(1), c.stream, \
+            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF), c.stream, \
                                x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
         else                                                                                          \
-            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(1), c.stream, \
+            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF), c.stream, \
                                x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
         return true;
     switch (shift) {
@@ -70,44 +70,66 @@ int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int ho
     return 0;
 }
 
-int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int sided, double scale, double *out) {
+int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int sided, double scale, double *out,
+                        int sym) {
     const int n = xf.tb.n;
     hipLaunchKernelGGL(k_welch_finish, dim3((n + SP_FIN_BINS - 1) / SP_FIN_BINS), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
-                       c.stream, partial, G, xf.L, n, sided, scale, out);
+                       c.stream, partial, G, xf.L, n, sided, scale, out, sym);
     return 0;
 }
 
-// ---- one-pass detrend epilogue ------------------------------------------------------------------
-int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, double *part, float *trend) {
-    if (cplx) hipLaunchKernelGGL((k_op_estimate<true>), dim3(SP_EST_RUNS), dim3(256), 0, c.stream, x, nsig, part);
-    else hipLaunchKernelGGL((k_op_estimate<false>), dim3(SP_EST_RUNS), dim3(256), 0, c.stream, x, nsig, part);
-    hipLaunchKernelGGL(k_op_estimate_fin, dim3(1), dim3(64), 0, c.stream, part, nsig, trend);
+// real input, two frames per transform (power only); rp partitions PAIRS of frames
+int launch_welch_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
+                    const Xf &xf, float *partial, const RunPart &rp) {
+#define M_(XT)                                                                                        \
+    if (lin) hipLaunchKernelGGL((k_welch_rp<XT, true>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, \
+                                win, hop, nframes, rp.fpg, trend, xf.tb, partial);                    \
+    else hipLaunchKernelGGL((k_welch_rp<XT, false>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, \
+                            win, hop, nframes, rp.fpg, trend, xf.tb, partial);
+    SP_DISPATCH_X(xf, M_)
+#undef M_
     return 0;
 }
 
-// A[k] raw sums, Sl[j] block sums, tot = sum_{i<nmean}(x - mu0)
+// ---- one-pass detrend epilogue: 4 launches (estimate | main kernel | two reductions | totals) + 1 at finish -------
+int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, double *, float *trend) {
+    if (cplx) hipLaunchKernelGGL((k_op_estimate<true>), dim3(1), dim3(1024), 0, c.stream, x, nsig, trend);
+    else hipLaunchKernelGGL((k_op_estimate<false>), dim3(1), dim3(1024), 0, c.stream, x, nsig, trend);
+    return 0;
+}
+
+// A[k] raw sums, Sl[j] block sums, tot = sum_{i<nmean}(x - mu0), local delta, plain sample sum
 int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *partial, const cf *spartial,
-                     int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st) {
+                     int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st, double *sum_out) {
     const int N = xf.L, H = hop, r = N / H;
     hipLaunchKernelGGL(k_welch_finish, dim3((N + SP_FIN_BINS - 1) / SP_FIN_BINS), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
-                       c.stream, partial, G, N, N, (int)SIDED_RAW, 1.0, st.A);
+                       c.stream, partial, G, N, N, (int)SIDED_RAW, 1.0, st.A, 0);
     hipLaunchKernelGGL(k_op_reduce_s, dim3((H + 31) / 32), dim3(1024), 0, c.stream, spartial, G, H, st.Sl);
-    if (cplx) hipLaunchKernelGGL((k_op_total<true>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot);
-    else hipLaunchKernelGGL((k_op_total<false>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot);
+    if (cplx) hipLaunchKernelGGL((k_op_total<true>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot, st.dlt, sum_out);
+    else hipLaunchKernelGGL((k_op_total<false>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot, st.dlt, sum_out);
     return 0;
 }
 
-// dlt, cw = w*c, B = FFT(cw) (in place), combine -> out
+// c -> B = FFT(w c) -> combine, one workgroup
 int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, OnePass st,
-                     const double *mean_in, int64_t nmean, const Xf &xf, int hop, int64_t nframes, cf *cw, const cf *Wf,
+                     const double *mean_in, int64_t nmean, const Xf &xf, int hop, int64_t nframes, cf *, const cf *Wf,
                      int sided, double scale, double *out) {
-    const int N = xf.L, H = hop, r = N / H;
-    hipLaunchKernelGGL(k_op_delta, dim3(1), dim3(64), 0, c.stream, st.tot, nmean, mean_in, trend, st.dlt);
-    if (cplx) hipLaunchKernelGGL((k_op_cw<true>), dim3((N + 255) / 256), dim3(256), 0, c.stream, x, trend, win, st.Sl, N, H, r, nframes, cw);
-    else hipLaunchKernelGGL((k_op_cw<false>), dim3((N + 255) / 256), dim3(256), 0, c.stream, x, trend, win, st.Sl, N, H, r, nframes, cw);
-    if (launch_fft_c2c(c, cw, cw, 1, 0, xf)) return -1;
-    hipLaunchKernelGGL(k_op_combine, dim3((N + 255) / 256), dim3(256), 0, c.stream, st.A, cw, Wf, st.dlt, N, nframes, sided,
-                       scale, out);
+    (void)nmean;
+    const int H = hop, r = xf.L / H;
+#define FIN_(NN)                                                                                      \
+    case NN:                                                                                          \
+        if (cplx)                                                                                     \
+            hipLaunchKernelGGL((k_op_finish<NN, true>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
+                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, sided, scale, xf.tb, out); \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_op_finish<NN, false>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
+                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, sided, scale, xf.tb, out); \
+        break;
+    switch (xf.L) {
+        FIN_(256) FIN_(512) FIN_(1024) FIN_(2048) FIN_(4096) FIN_(8192)
+        default: return -1;
+    }
+#undef FIN_
     return 0;
 }
 

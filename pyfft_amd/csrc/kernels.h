@@ -42,6 +42,8 @@ template <int N> struct XfPow2 {
     WgFft<N, false> f;
     __device__ __forceinline__ void init(const XfTables &tb, int tid) { f.load_twiddles(tb.tw, tid); }
     __device__ __forceinline__ void fwd(cf (&v)[C::R], cf *lds, int tid, int) const { f.template run<true>(v, lds, lds, tid); }
+    // two exchange images (ping-pong): one barrier per exchange instead of two
+    __device__ __forceinline__ void fwd2(cf (&v)[C::R], cf *lds_a, cf *lds_b, int tid) const { f.template run<false>(v, lds_a, lds_b, tid); }
 };
 
 template <int L_> struct XfBlue {
@@ -217,6 +219,58 @@ __global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Real input, power only: two consecutive real frames ride in one complex transform, z = f_g + i f_{g+1}.
+// |X_g|^2 + |X_{g+1}|^2 = (|Z[k]|^2 + |Z[n-k]|^2) / 2, so the kernel just accumulates |Z|^2 and the finish kernel
+// symmetrises (k_welch_finish with `sym`).  A lone last frame has a zero imaginary part, for which the same
+// formula holds.  Halves the transform count of real-valued Welch PSDs.
+// ------------------------------------------------------------------------------------------
+template <class X, bool LIN>
+__global__ __launch_bounds__(X::C::WG) void k_welch_rp(const float *__restrict__ x, const float *__restrict__ win, int hop,
+                                                        int64_t nframes, int64_t ppg /*pairs per group*/,
+                                                        const float *__restrict__ trend, XfTables tb,
+                                                        float *__restrict__ partial) {
+    SP_KERNEL_PROLOGUE(X)
+    float w[C::R], acc[C::R];
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        const int i = tid + C::T * t;
+        w[t] = (X::EXACT || i < n) ? win[i] : 0.f;
+        acc[t] = 0.f;
+    }
+    const Trend tr = load_trend(trend);
+    const int64_t npairs = (nframes + 1) / 2;
+    const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
+    const int64_t p0 = gid * ppg;
+    for (int64_t i = 0; i < ppg; ++i) {
+        const int64_t p = p0 + i;
+        const float keep = p < npairs ? 1.f : 0.f;
+        const int64_t ga = 2 * (p < npairs ? p : npairs - 1);
+        const bool has_b = ga + 1 < nframes;
+        const int64_t base_a = ga * hop, base_b = (has_b ? ga + 1 : ga) * hop;
+        const float kb = has_b ? 1.f : 0.f;
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int j = tid + C::T * t;
+            const int jj = (X::EXACT || j < n) ? j : n - 1;
+            v[t] = mk(x[base_a + jj], x[base_b + jj]);
+        }
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int j = tid + C::T * t;
+            const cf a = detrended<LIN>(mk(v[t].x, 0.f), tr, base_a + j);
+            const cf b = detrended<LIN>(mk(v[t].y, 0.f), tr, base_b + j);
+            v[t] = mk(w[t] * a.x, kb * w[t] * b.x);
+        }
+        xf.fwd(v, lds, tid, n);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) acc[t] += keep * cnorm(v[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) partial[gid * X::L + tid + C::T * t] = acc[t];
+}
+
+// ------------------------------------------------------------------------------------------
 // The metric kernel: power-of-two n = N, hop = SHIFT*T (the hop is a whole number of register
 // slots), so a frame advances by renaming registers: the overlapped part of the next frame is
 // carried in registers and only the SHIFT new slots per thread are read from HBM -- every sample
@@ -228,6 +282,11 @@ __global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, 
 // frame's last hop-block (time domain, SHIFT slots).  From those block sums the epilogue rebuilds
 // sum_g X_g[k] and the exact mean and applies  |X - dW|^2 = |X|^2 - 2Re(conj(dW) X) + |dW|^2.
 // ------------------------------------------------------------------------------------------
+// exchange images per transform in the carry kernel: 2 = ping-pong (2 barriers per frame instead of 4, 66 KiB LDS);
+// measured no faster than 1 (0.66 vs 0.64 ms at the metric shape), so the smaller footprint is kept
+#ifndef SP_CARRY_NBUF
+#define SP_CARRY_NBUF 1
+#endif
 // (no min-waves hint: capping at 168 VGPRs makes hipcc spill the window registers and reload them inside the
 //  frame loop behind vmcnt(0) waits, which also drains the prefetch loads -- measured 2x slower)
 template <int N, bool CPLX, int SHIFT, bool ONEPASS>
@@ -285,7 +344,14 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
         cf v[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = w[t] * raw[t];
-        xf.fwd(v, lds, tid, N);
+        if (SP_CARRY_NBUF == 2) {
+            // ping-pong exchange images: with an odd number of exchanges per transform the roles swap every frame
+            cf *lds_b = lds + C::FPW * C::LDS_PER;
+            const bool swap = ((C::PL::NP - 1) & 1) && (i & 1);
+            xf.fwd2(v, swap ? lds_b : lds, swap ? lds : lds_b, tid);
+        } else {
+            xf.fwd(v, lds, tid, N);
+        }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) acc[t] = UNI ? acc[t] + cnorm(v[t]) : acc[t] + keep * cnorm(v[t]);
         // advance one hop: rename registers, detrend the samples that just arrived
@@ -347,10 +413,12 @@ static __global__ __launch_bounds__(1024) void k_op_reduce_s(const cf *__restric
 
 // tot = sum_{i < nmean} (x[i] - mu0): block sums cover [(r-1)H, (M+r-1)H); add the head blocks and fix the end.
 // one block of 1024 threads.
+// also: sum_out = tot + nmean*mu0 (the shard's plain sample sum) and dlt = tot/nmean (delta for the shard's own mean)
 template <bool CPLX>
 static __global__ __launch_bounds__(1024) void k_op_total(const void *__restrict__ x, const float *__restrict__ trend,
                                                            const double *__restrict__ Sl, int H, int r, int64_t M,
-                                                           int64_t nmean, double *__restrict__ tot) {
+                                                           int64_t nmean, double *__restrict__ tot,
+                                                           double *__restrict__ dlt, double *__restrict__ sum_out) {
     __shared__ double sh[2][1024];
     const cf mu = mk(trend[0], trend[1]);
     double a = 0, b = 0;
@@ -391,6 +459,10 @@ static __global__ __launch_bounds__(1024) void k_op_total(const void *__restrict
     if (threadIdx.x == 0) {
         tot[0] = sh[0][0];
         tot[1] = sh[1][0];
+        dlt[0] = sh[0][0] / (double)nmean;
+        dlt[1] = sh[1][0] / (double)nmean;
+        sum_out[0] = sh[0][0] + (double)nmean * (double)trend[0];
+        sum_out[1] = sh[1][0] + (double)nmean * (double)trend[1];
     }
 }
 
@@ -431,6 +503,63 @@ static __global__ void k_op_cw(const void *__restrict__ x, const float *__restri
     cw[nidx] = mk((float)(wn * a), (float)(wn * b));
 }
 
+// one workgroup: c[n] from the block sums, B = FFT(w c), then the combine below -- replaces k_op_cw + k_fft_c2c +
+// k_op_combine (three launches) for every N the carry kernel supports.  mean_in != null overrides the local delta.
+template <int N, bool CPLX>
+static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *__restrict__ x, const float *__restrict__ trend,
+                                                                    const float *__restrict__ win,
+                                                                    const double *__restrict__ Sl,
+                                                                    const double *__restrict__ A, const cf *__restrict__ Wf,
+                                                                    const double *__restrict__ dlt_local,
+                                                                    const double *__restrict__ mean_in, int H, int r,
+                                                                    int64_t M, int sided, double scale, XfTables tb,
+                                                                    double *__restrict__ out) {
+    using X = XfPow2<N>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
+    const cf mu = mk(trend[0], trend[1]);
+    double dr, di;
+    if (mean_in) {
+        dr = mean_in[0] - (double)trend[0];
+        di = mean_in[1] - (double)trend[1];
+    } else {
+        dr = dlt_local[0];
+        di = dlt_local[1];
+    }
+    cf v[C::R];
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        const int nidx = tid + C::T * t;
+        const int q = nidx / H, j = nidx % H;
+        double a = Sl[2 * j], b = Sl[2 * j + 1];
+        for (int bb = q; bb <= r - 2; ++bb) {
+            const cf s = load_sample(x, (int64_t)bb * H + j, CPLX) - mu;
+            a += s.x;
+            b += s.y;
+        }
+        for (int64_t bb = M + q; bb <= M + r - 2; ++bb) {
+            const cf s = load_sample(x, bb * H + j, CPLX) - mu;
+            a -= s.x;
+            b -= s.y;
+        }
+        const double wn = (double)win[nidx];
+        v[t] = (grp == 0) ? mk((float)(wn * a), (float)(wn * b)) : mk(0.f, 0.f);
+    }
+    xf.fwd(v, lds, tid, N);
+    if (grp == 0) {
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int k = tid + C::T * t;
+            const int slot = bin_slot(k, N, sided);
+            if (slot < 0) continue;
+            const double wr = Wf[k].x, wi = Wf[k].y;
+            const double er = dr * wr - di * wi, ei = dr * wi + di * wr;       // d * Wf[k]
+            const double p = A[k] - 2.0 * (er * (double)v[t].x + ei * (double)v[t].y) + (double)M * (er * er + ei * ei);
+            out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
+        }
+    }
+}
+
 // out[slot] = scale * doubling * (A[k] - 2 Re(conj(d Wf[k]) B[k]) + M |d Wf[k]|^2)
 static __global__ void k_op_combine(const double *__restrict__ A, const cf *__restrict__ B, const cf *__restrict__ Wf,
                                     const double *__restrict__ dlt, int N, int64_t M, int sided, double scale,
@@ -448,25 +577,28 @@ static __global__ void k_op_combine(const double *__restrict__ A, const cf *__re
 }
 
 // mean estimate mu0: 64 contiguous runs of <= 1024 samples spread over the whole signal (robust to drift, and each
-// run is a coalesced read).  part[64][2] doubles; the finishing block writes trend[4] = (mu0, 0 slope).
+// run is a coalesced read); one block of 1024 threads writes trend[4] = (mu0, 0 slope).
 #define SP_EST_RUNS 64
 #define SP_EST_LEN 1024
 template <bool CPLX>
-static __global__ __launch_bounds__(256) void k_op_estimate(const void *__restrict__ x, int64_t nsig,
-                                                             double *__restrict__ part) {
-    __shared__ double sh[2][256];
+static __global__ __launch_bounds__(1024) void k_op_estimate(const void *__restrict__ x, int64_t nsig,
+                                                              float *__restrict__ trend) {
+    __shared__ double sh[2][1024];
     const int64_t len = nsig / SP_EST_RUNS < SP_EST_LEN ? nsig / SP_EST_RUNS : SP_EST_LEN;     // may be 0 for tiny signals
-    const int64_t start = (nsig / SP_EST_RUNS) * blockIdx.x;
+    const int64_t pitch = nsig / SP_EST_RUNS;
     double a = 0, b = 0;
-    for (int64_t i = threadIdx.x; i < len; i += 256) {
-        const cf v = load_sample(x, start + i, CPLX);
-        a += v.x;
-        b += v.y;
-    }
+    // thread t covers element (t % 64 + 64 j) of runs (t / 64) + 16 m: 64 lanes read 64 consecutive samples
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int r = wv; r < SP_EST_RUNS; r += 16)
+        for (int64_t i = lane; i < len; i += 64) {
+            const cf v = load_sample(x, pitch * r + i, CPLX);
+            a += v.x;
+            b += v.y;
+        }
     sh[0][threadIdx.x] = a;
     sh[1][threadIdx.x] = b;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
             sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
             sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
@@ -474,22 +606,9 @@ static __global__ __launch_bounds__(256) void k_op_estimate(const void *__restri
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        part[2 * blockIdx.x] = sh[0][0];
-        part[2 * blockIdx.x + 1] = sh[1][0];
-    }
-}
-
-static __global__ void k_op_estimate_fin(const double *__restrict__ part, int64_t nsig, float *__restrict__ trend) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const int64_t len = nsig / SP_EST_RUNS < SP_EST_LEN ? nsig / SP_EST_RUNS : SP_EST_LEN;
-        double a = 0, b = 0;
-        for (int r = 0; r < SP_EST_RUNS; ++r) {
-            a += part[2 * r];
-            b += part[2 * r + 1];
-        }
         const double cnt = (double)(len * SP_EST_RUNS);
-        trend[0] = cnt > 0 ? (float)(a / cnt) : 0.f;
-        trend[1] = cnt > 0 ? (float)(b / cnt) : 0.f;
+        trend[0] = cnt > 0 ? (float)(sh[0][0] / cnt) : 0.f;
+        trend[1] = cnt > 0 ? (float)(sh[1][0] / cnt) : 0.f;
         trend[2] = 0.f;
         trend[3] = 0.f;
     }
@@ -500,9 +619,10 @@ static __global__ void k_op_estimate_fin(const double *__restrict__ part, int64_
 // (the reduction is latency-bound); deterministic order.
 #define SP_FIN_BINS 32
 #define SP_FIN_SLICES 32
+// sym != 0 (real-pair kernels): the bin sum is (S[k] + S[(n-k) % n]) / 2.
 static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_welch_finish(const float *__restrict__ partial, int64_t G,
                                                                                      int L, int n, int sided, double scale,
-                                                                                     double *__restrict__ out) {
+                                                                                     double *__restrict__ out, int sym) {
     __shared__ double sh[SP_FIN_SLICES][SP_FIN_BINS];
     const int lane = threadIdx.x % SP_FIN_BINS, sl = threadIdx.x / SP_FIN_BINS;
     const int k = blockIdx.x * SP_FIN_BINS + lane;
@@ -518,6 +638,13 @@ static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_welch_fin
             s3 += (double)a3;
         }
         for (; g < G; g += SP_FIN_SLICES) s0 += (double)partial[g * L + k];
+        if (sym) {
+            const int km = k == 0 ? 0 : n - k;
+            double m = 0.0;
+            for (int64_t g2 = sl; g2 < G; g2 += SP_FIN_SLICES) m += (double)partial[g2 * L + km];
+            s0 = 0.5 * ((s0 + s1) + (s2 + s3) + m);
+            s1 = s2 = s3 = 0.0;
+        }
     }
     sh[sl][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -687,6 +814,81 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
                 } else {
                     const float a = bin_doubled(k, n, sided) ? amp * 1.41421356237309504880f : amp;
                     reinterpret_cast<cf *>(out)[g * nb + slot] = a * v[t];
+                }
+            }
+        }
+    }
+}
+
+// Real input STFT, two frames per transform: z = f_g + i f_{g+1};  X_g = (Z[k] + conj Z[n-k]) / 2,
+// X_{g+1} = (Z[k] - conj Z[n-k]) / (2i).  The mirror comes from one more LDS exchange (linear image, reversed read).
+// Power-of-two n only (mirror index by masking); the other lengths use k_stft.
+template <int N, bool LIN>
+__global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restrict__ x, const float *__restrict__ win,
+                                                           int hop, int64_t nframes, int64_t ppg,
+                                                           const float *__restrict__ trend, XfTables tb, int sided,
+                                                           float amp, int out_power, void *__restrict__ out,
+                                                           double *__restrict__ pseg) {
+    using X = XfPow2<N>;
+    SP_KERNEL_PROLOGUE(X)
+    float w[C::R];
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) w[t] = win[tid + C::T * t];
+    const Trend tr = load_trend(trend);
+    const int nb = nbins_of(n, sided);
+    const int64_t npairs = (nframes + 1) / 2;
+    const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
+    const int64_t p0 = gid * ppg;
+    for (int64_t i = 0; i < ppg; ++i) {
+        const int64_t p = p0 + i;
+        const bool act = p < npairs;
+        const int64_t ga = 2 * (act ? p : npairs - 1);
+        const bool has_b = ga + 1 < nframes;
+        const int64_t base_a = ga * hop, base_b = (has_b ? ga + 1 : ga) * hop;
+        cf v[C::R];
+        float pwa = 0.f, pwb = 0.f;
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int j = tid + C::T * t;
+            v[t] = mk(x[base_a + j], x[base_b + j]);
+        }
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int j = tid + C::T * t;
+            const cf a = detrended<LIN>(mk(v[t].x, 0.f), tr, base_a + j);
+            const cf b = detrended<LIN>(mk(v[t].y, 0.f), tr, base_b + j);
+            v[t] = mk(w[t] * a.x, w[t] * b.x);
+            const float e = (j == 0 || j == N - 1) ? 0.5f : 1.f;
+            pwa += e * v[t].x * v[t].x;
+            pwb += e * v[t].y * v[t].y;
+        }
+        if (pseg != nullptr && act) {
+            atomicAdd(&pseg[ga], (double)pwa);
+            if (has_b) atomicAdd(&pseg[ga + 1], (double)pwb);
+        }
+        xf.fwd(v, lds, tid, N);
+        // mirror exchange
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) lds[tid + C::T * t] = v[t];
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int k = tid + C::T * t;
+                const int slot = bin_slot(k, N, sided);
+                if (slot < 0) continue;
+                const cf zm = lds[(N - k) & (N - 1)];
+                const cf z = v[t];
+                const cf xa = mk(0.5f * (z.x + zm.x), 0.5f * (z.y - zm.y));          // (Z + conj Zm)/2
+                const cf xb = mk(0.5f * (z.y + zm.y), -0.5f * (z.x - zm.x));         // (Z - conj Zm)/(2i)
+                if (out_power) {
+                    reinterpret_cast<float *>(out)[ga * nb + slot] = amp * cnorm(xa);
+                    if (has_b) reinterpret_cast<float *>(out)[(ga + 1) * nb + slot] = amp * cnorm(xb);
+                } else {
+                    const float a = bin_doubled(k, N, sided) ? amp * 1.41421356237309504880f : amp;
+                    reinterpret_cast<cf *>(out)[ga * nb + slot] = a * xa;
+                    if (has_b) reinterpret_cast<cf *>(out)[(ga + 1) * nb + slot] = a * xb;
                 }
             }
         }

@@ -67,11 +67,16 @@ int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int ho
                  const char **kname);
 int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, double *part, float *trend);
 int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *partial, const cf *spartial,
-                     int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st);
+                     int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st, double *sum_out);
 int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, OnePass st,
                      const double *mean_in, int64_t nmean, const Xf &xf, int hop, int64_t nframes, cf *cw, const cf *Wf,
                      int sided, double scale, double *out);
-int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int sided, double scale, double *out);
+int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int sided, double scale, double *out,
+                        int sym = 0);
+int launch_welch_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
+                    const Xf &xf, float *partial, const RunPart &rp);
+int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
+                   const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg);
 int launch_csd(LaunchCtx c, const void *x, const void *y, bool cplx, int nch, int64_t y_ld, const float *win, int hop,
                int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,
                const RunPart &rp);

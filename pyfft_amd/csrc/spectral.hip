@@ -512,9 +512,7 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
         LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,
                                spartial, &g.last_kernel));
     }
-    LAUNCHCHK(launch_op_reduce(lc(), xd, cplx, tb.f, partial, spartial, rp.groups, xf, hop, nframes, nmean, st));
-    hipLaunchKernelGGL(k_op_sum, dim3(1), dim3(64), 0, g.stream, st.tot, tb.f, nmean, sum_d);
-    HIPCHK(hipGetLastError());
+    LAUNCHCHK(launch_op_reduce(lc(), xd, cplx, tb.f, partial, spartial, rp.groups, xf, hop, nframes, nmean, st, sum_d));
     g_pend.valid = true;
     g_pend.xd = xd;
     g_pend.cplx = cplx;
@@ -733,7 +731,8 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         out_d = (double *)g.out0.p;
     }
     const bool allow_carry = !env_flag("SP_WELCH_GENERIC");
-    if (detrend == SP_DETREND_MEAN && allow_carry && !env_flag("SP_WELCH_TWOPASS") && welch_carry_eligible(xf, hop, false)) {
+    if (cplx && detrend == SP_DETREND_MEAN && allow_carry && !env_flag("SP_WELCH_TWOPASS") &&
+        welch_carry_eligible(xf, hop, false)) {
         // global-mean detrend in ONE pass over the signal (estimate + exact correction in the epilogue)
         if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nsig)) return -1;
         if (welch_finish_locked(nullptr, nframes, sided, scale, out_d)) return -1;
@@ -743,15 +742,23 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         TrendBuf tb;
         if (get_trendbuf(1, &tb)) return -1;
         if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
-        const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+        const bool pair = !cplx && nframes >= 2 && !env_flag("SP_NO_REALPAIR");
+        const RunPart rp = run_partition(xf.L, pair ? (nframes + 1) / 2 : nframes, g.ncu);
         if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
         float *partial = (float *)g.work.p;
         {
             ProfScope ps;
-            LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, partial, rp,
-                                   allow_carry, nullptr, &g.last_kernel));
+            if (pair) {
+                // real input: two frames per complex transform, |Z|^2 accumulated, symmetrised by the finish kernel
+                LAUNCHCHK(launch_welch_rp(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf,
+                                          partial, rp));
+                g.last_kernel = "k_welch_rp";
+            } else {
+                LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, partial,
+                                       rp, allow_carry, nullptr, &g.last_kernel));
+            }
         }
-        LAUNCHCHK(launch_welch_finish(lc(), partial, rp.groups, xf, sided, scale / (double)nframes, out_d));
+        LAUNCHCHK(launch_welch_finish(lc(), partial, rp.groups, xf, sided, scale / (double)nframes, out_d, pair ? 1 : 0));
     }
     if (!mem) {
         HIPCHK(hipMemcpyAsync(pxx_out, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
@@ -962,9 +969,16 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
         fm = g.work.p;
     }
     if (pseg_d) HIPCHK(hipMemsetAsync(pseg_d, 0, sizeof(double) * (size_t)nframes, g.stream));
-    const RunPart rp = run_partition(xf.L, nframes, g.ncu);
-    LAUNCHCHK(launch_stft(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, sided,
-                          (float)amp_scale, out_kind, fm, pseg_d));
+    const bool pair = !cplx && !xf.blue && xf.L >= 32 && nframes >= 2 && !env_flag("SP_NO_REALPAIR");
+    if (pair) {
+        const RunPart rp = run_partition(xf.L, (nframes + 1) / 2, g.ncu);
+        LAUNCHCHK(launch_stft_rp(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, sided,
+                                 (float)amp_scale, out_kind, fm, pseg_d));
+    } else {
+        const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+        LAUNCHCHK(launch_stft(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, sided,
+                              (float)amp_scale, out_kind, fm, pseg_d));
+    }
     if (out_major == 1) LAUNCHCHK(launch_transpose(lc(), fm, fin, nframes, (int64_t)nb, (int)osz));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(out, fin, obytes, hipMemcpyDeviceToHost, g.stream));

@@ -283,6 +283,47 @@ def test_dist_world1_on_device(E):
     assert relerr(h.cpu().numpy(), O.hilbert(x.real[: 4 * 1024].reshape(4, 1024).astype(np.float64))) < 1e-4
 
 
+def test_real_pair_packing_equals_plain_path(E):
+    """real input: the two-frames-per-transform kernels (Welch power, STFT) against the one-frame kernels and the
+    oracle; odd and even frame counts, one- and two-sided, non power-of-two Welch length"""
+    import os
+    rng = np.random.default_rng(21)
+    for nfft, hop, extra in ((1024, 256, 41), (2048, 512, 40), (256, 256, 7), (1000, 500, 13)):
+        nsig = nfft + hop * extra + 3
+        x = (rng.standard_normal(nsig) + 0.4).astype(np.float32)
+        M = (nsig - nfft) // hop + 1
+        win = O.windows("Hamming", nwins=nfft)
+        ref = O.welch_psd_stream(x, win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+        for sided in (E.SIDED_TWO, E.SIDED_ONE):
+            a = E.welch_psd(x, win, hop, M, detrend=True, sided=sided, scale=1.0)
+            assert E.profile_last_kernel() == "k_welch_rp"
+            os.environ["SP_NO_REALPAIR"] = "1"
+            try:
+                b = E.welch_psd(x, win, hop, M, detrend=True, sided=sided, scale=1.0)
+                assert E.profile_last_kernel() != "k_welch_rp"
+            finally:
+                del os.environ["SP_NO_REALPAIR"]
+            np.testing.assert_allclose(a, b, rtol=3e-5, atol=1e-7 * b.max())
+        np.testing.assert_allclose(E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0), ref, rtol=2e-4,
+                                   atol=1e-6 * ref.max())
+        if nfft & (nfft - 1):
+            continue
+        for sided in (E.SIDED_ONE, E.SIDED_RAW):
+            Xa, pa = E.stft_frames(x, win, hop, M, detrend=True, sided=sided, amp_scale=0.5, want_pseg=True)
+            os.environ["SP_NO_REALPAIR"] = "1"
+            try:
+                Xb, pb = E.stft_frames(x, win, hop, M, detrend=True, sided=sided, amp_scale=0.5, want_pseg=True)
+            finally:
+                del os.environ["SP_NO_REALPAIR"]
+            assert np.max(np.abs(Xa - Xb)) <= 2e-6 * np.abs(Xb).max()
+            np.testing.assert_allclose(pa, pb, rtol=1e-5)
+        Pa, _ = E.stft_frames(x, win, hop, M, detrend=False, sided=E.SIDED_RAW, amp_scale=1.0, power=True, bin_major=True)
+        xd = x.astype(np.float64)
+        idx = (np.arange(M) * hop)[:, None] + np.arange(nfft)[None, :]
+        refp = (np.abs(np.fft.fft(win * xd[idx], axis=-1)) ** 2).T
+        np.testing.assert_allclose(Pa, refp, rtol=3e-4, atol=2e-6 * refp.max())
+
+
 def test_welch_errors(E):
     from pyfft_amd._ffi import SpectralError
     x = np.zeros(1000, dtype=np.float32)
