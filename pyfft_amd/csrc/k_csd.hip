@@ -30,6 +30,37 @@ int launch_csd_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf
     return 0;
 }
 
+// real x, y, power-of-two n >= 32: one transform per (frame, channel)
+bool csd_rp_eligible(const Xf &xf) { return !xf.blue && xf.L >= 32 && xf.L <= 8192; }
+
+int launch_csd_rp(LaunchCtx c, const float *x, const float *y, int nch, int64_t y_ld, const float *win, int hop,
+                  int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,
+                  const RunPart &rp) {
+#define RP_(NN)                                                                                       \
+    case NN:                                                                                          \
+        if (lin) hipLaunchKernelGGL((k_welch_csd_rp<NN, true>), dim3(rp.blocks, nch), dim3(WgCfg<NN>::WG),       \
+                                    WgCfg<NN>::lds_bytes(1), c.stream, x, y, y_ld, win, hop, nframes, rp.fpg, trend_x,  \
+                                    trend_y, xf.tb, partial, rp.groups);                              \
+        else hipLaunchKernelGGL((k_welch_csd_rp<NN, false>), dim3(rp.blocks, nch), dim3(WgCfg<NN>::WG),          \
+                                WgCfg<NN>::lds_bytes(1), c.stream, x, y, y_ld, win, hop, nframes, rp.fpg, trend_x,      \
+                                trend_y, xf.tb, partial, rp.groups);                                  \
+        break;
+    switch (xf.L) {
+        RP_(32) RP_(64) RP_(128) RP_(256) RP_(512) RP_(1024) RP_(2048) RP_(4096) RP_(8192)
+        default: return -1;
+    }
+#undef RP_
+    return 0;
+}
+
+int launch_csd_rp_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
+                         double *pxx, double *pyy, double *pxy) {
+    const int n = xf.tb.n;
+    hipLaunchKernelGGL(k_csd_rp_finish, dim3((n + SP_FIN_BINS - 1) / SP_FIN_BINS, nch), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
+                       c.stream, partial, G, n, nch, sided, scale, pxx, pyy, pxy);
+    return 0;
+}
+
 int launch_csdm_transpose(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int64_t mc, int nb) {
     dim3 grid((unsigned)((nb + 31) / 32), (unsigned)((mc + 31) / 32), (unsigned)nch);
     hipLaunchKernelGGL(k_csdm_transpose, grid, dim3(32, 8), 0, c.stream, Xs, Xt, nch, mc, nb);

@@ -724,6 +724,116 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_csd(const void *__restrict__
     }
 }
 
+// Real x and y: z = w (x - mx) + i w (y_c - my) -> one transform per (frame, channel).  With Zm = Z[n-k]:
+//   X = (Z + conj Zm)/2,  Y = (Z - conj Zm)/(2i)
+//   |X|^2 = (|Z|^2 + |Zm|^2 + 2 Re(Z Zm))/4,  |Y|^2 = (|Z|^2 + |Zm|^2 - 2 Re(Z Zm))/4,
+//   Y conj(X) = Im(Z Zm)/2 - i (|Z|^2 - |Zm|^2)/4
+// so the kernel accumulates a[k] = |Z[k]|^2 and c[k] = Z[k] Zm[k] (mirror through one LDS exchange) and the finish
+// kernel does the algebra.  partial per (channel, group): [3][L] = a, Re c, Im c.  Power-of-two n.
+template <int N, bool LIN>
+__global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd_rp(const float *__restrict__ x, const float *__restrict__ y,
+                                                                int64_t y_ld, const float *__restrict__ win, int hop,
+                                                                int64_t nframes, int64_t fpg,
+                                                                const float *__restrict__ trend_x,
+                                                                const float *__restrict__ trend_y, XfTables tb,
+                                                                float *__restrict__ partial, int64_t groups_total) {
+    using X = XfPow2<N>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
+    const int ch = blockIdx.y;
+    float w[C::R], aa[C::R];
+    cf cc[C::R];
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        w[t] = win[tid + C::T * t];
+        aa[t] = 0.f;
+        cc[t] = mk(0.f, 0.f);
+    }
+    const Trend trx = load_trend(trend_x), try_ = load_trend(trend_y + 4 * ch);
+    const float *yc = y + (int64_t)ch * y_ld;
+    const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
+    const int64_t g0 = gid * fpg;
+    for (int64_t i = 0; i < fpg; ++i) {
+        const int64_t g = g0 + i;
+        const float keep = g < nframes ? 1.f : 0.f;
+        const int64_t base = (g < nframes ? g : nframes - 1) * hop;
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int64_t idx = base + tid + C::T * t;
+            v[t] = mk(x[idx], yc[idx]);
+        }
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int64_t idx = base + tid + C::T * t;
+            const cf a = detrended<LIN>(mk(v[t].x, 0.f), trx, idx);
+            const cf b = detrended<LIN>(mk(v[t].y, 0.f), try_, idx);
+            v[t] = mk(w[t] * a.x, w[t] * b.x);
+        }
+        xf.fwd(v, lds, tid, N);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) lds[tid + C::T * t] = v[t];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int k = tid + C::T * t;
+            const cf zm = lds[(N - k) & (N - 1)];
+            aa[t] += keep * cnorm(v[t]);
+            cc[t] = cc[t] + keep * cmul(v[t], zm);
+        }
+    }
+    float *p = partial + ((int64_t)ch * groups_total + gid) * 3 * N;
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        const int k = tid + C::T * t;
+        p[k] = aa[t];
+        p[N + k] = cc[t].x;
+        p[2 * N + k] = cc[t].y;
+    }
+}
+
+static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_rp_finish(const float *__restrict__ partial,
+                                                                               int64_t G, int n, int nch, int sided,
+                                                                               double scale, double *__restrict__ pxx,
+                                                                               double *__restrict__ pyy,
+                                                                               double *__restrict__ pxy) {
+    __shared__ double sh[4][SP_FIN_SLICES][SP_FIN_BINS];
+    const int lane = threadIdx.x % SP_FIN_BINS, sl = threadIdx.x / SP_FIN_BINS;
+    const int k = blockIdx.x * SP_FIN_BINS + lane;
+    const int ch = blockIdx.y;
+    const int nb = nbins_of(n, sided);
+    double s[4] = {0, 0, 0, 0};       // a[k], a[km], Re c[k], Im c[k]
+    const float *p = partial + (int64_t)ch * G * 3 * n;
+    if (k < n) {
+        const int km = k == 0 ? 0 : n - k;
+        for (int64_t g = sl; g < G; g += SP_FIN_SLICES) {
+            s[0] += (double)p[(g * 3 + 0) * n + k];
+            s[1] += (double)p[(g * 3 + 0) * n + km];
+            s[2] += (double)p[(g * 3 + 1) * n + k];
+            s[3] += (double)p[(g * 3 + 2) * n + k];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[j][sl][lane] = s[j];
+    __syncthreads();
+    if (sl == 0 && k < n) {
+        const int slot = bin_slot(k, n, sided);
+        if (slot >= 0) {
+            double t[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < SP_FIN_SLICES; ++q) t[j] += sh[j][q][lane];
+            const double m = scale * (bin_doubled(k, n, sided) ? 2.0 : 1.0);
+            if (ch == 0) pxx[slot] = 0.25 * (t[0] + t[1] + 2.0 * t[2]) * m;
+            pyy[(int64_t)ch * nb + slot] = 0.25 * (t[0] + t[1] - 2.0 * t[2]) * m;
+            pxy[((int64_t)ch * nb + slot) * 2] = 0.5 * t[3] * m;
+            pxy[((int64_t)ch * nb + slot) * 2 + 1] = -0.25 * (t[0] - t[1]) * m;
+        }
+    }
+}
+
 // out layouts: pxx[nbins] (from channel 0's copy), pyy[nch][nbins], pxy[nch][nbins][2]
 static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_finish(const float *__restrict__ partial, int64_t G,
                                                                             int L, int n, int nch, int sided,

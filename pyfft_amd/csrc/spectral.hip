@@ -859,9 +859,18 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     const RunPart rp = run_partition(xf.L, nframes, g.ncu, nch >= 8 ? 2 : 8);
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L * 4 * (size_t)nch)) return -1;
     float *partial = (float *)g.work.p;
-    LAUNCHCHK(launch_csd(lc(), xd, yd, cplx, nch, y_ld, (const float *)win_d, hop, nframes, tb.f, tb.f + 4, detrend == 2,
-                         xf, partial, rp));
-    LAUNCHCHK(launch_csd_finish(lc(), partial, rp.groups, xf, nch, sided, scale / (double)nframes, pxx_d, pyy_d, pxy_d));
+    if (!cplx && csd_rp_eligible(xf) && !env_flag("SP_NO_REALPAIR")) {
+        // real x, y: x + i y_c in one transform per (frame, channel)
+        LAUNCHCHK(launch_csd_rp(lc(), (const float *)xd, (const float *)yd, nch, y_ld, (const float *)win_d, hop, nframes,
+                                tb.f, tb.f + 4, detrend == 2, xf, partial, rp));
+        LAUNCHCHK(launch_csd_rp_finish(lc(), partial, rp.groups, xf, nch, sided, scale / (double)nframes, pxx_d, pyy_d,
+                                       pxy_d));
+    } else {
+        LAUNCHCHK(launch_csd(lc(), xd, yd, cplx, nch, y_ld, (const float *)win_d, hop, nframes, tb.f, tb.f + 4,
+                             detrend == 2, xf, partial, rp));
+        LAUNCHCHK(launch_csd_finish(lc(), partial, rp.groups, xf, nch, sided, scale / (double)nframes, pxx_d, pyy_d,
+                                    pxy_d));
+    }
     if (!mem) {
         HIPCHK(hipMemcpyAsync(pxx, pxx_d, sizeof(double) * nb, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipMemcpyAsync(pyy, pyy_d, sizeof(double) * nb * nch, hipMemcpyDeviceToHost, g.stream));

@@ -399,6 +399,26 @@ def test_csd_matrix(E, nch, nfft, hop, nsig):
     np.testing.assert_allclose(G[:, 0, 0].real, p0, rtol=1e-4, atol=1e-6 * p0.max())
 
 
+def test_welch_csd_real_pair_equals_plain(E):
+    import os
+    rng = np.random.default_rng(8)
+    n, nfft, hop = 30000, 1024, 256
+    k = np.arange(n)
+    x = (np.sin(0.21 * k) + 0.3 * rng.standard_normal(n) - 0.7).astype(np.float32)
+    y = np.stack([0.4 * np.sin(0.21 * k + 1.0) + 0.2 * rng.standard_normal(n) + c for c in range(3)]).astype(np.float32)
+    M = (n - nfft) // hop + 1
+    win = O.windows("Hanning", nwins=nfft)
+    for sided in (E.SIDED_ONE, E.SIDED_TWO, E.SIDED_RAW):
+        a = E.welch_csd(x, y, win, hop, M, detrend=True, sided=sided, scale=2.0)
+        os.environ["SP_NO_REALPAIR"] = "1"
+        try:
+            b = E.welch_csd(x, y, win, hop, M, detrend=True, sided=sided, scale=2.0)
+        finally:
+            del os.environ["SP_NO_REALPAIR"]
+        for u, v in zip(a, b):
+            assert np.max(np.abs(u - v)) <= 3e-5 * np.abs(v).max()
+
+
 # ---------------------------------------------------------------- A8/A9 STFT / specgram
 def test_stft_golden_f32(E):
     g = load_golden("stft_f32_n2048_ov75")
