@@ -69,7 +69,16 @@ int launch_csdm_transpose(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int64_t mc
 
 int launch_csdm_gemm(LaunchCtx c, const cf *Xt, int nch, int64_t mc, int nb, double *G) {
     const int nblk = (nch + SP_CM_B - 1) / SP_CM_B;
-    hipLaunchKernelGGL(k_csdm_gemm, dim3(nb, nblk * nblk), dim3(256), 0, c.stream, Xt, nch, mc, nblk, G);
+    // frame slices: enough workgroups (>= 8 per resident slot) that the last partial round costs little
+    const int64_t wgs = (int64_t)nb * (nblk * (nblk + 1) / 2);
+    int slices = (int)(((int64_t)c.ncu * 4 * 8 + wgs - 1) / wgs);
+    const int max_slices = (int)((mc + 4 * SP_CM_F - 1) / (4 * SP_CM_F));        // at least 128 frames per slice
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    int64_t fs = (mc + slices - 1) / slices;
+    fs = (fs + SP_CM_F - 1) / SP_CM_F * SP_CM_F;
+    slices = (int)((mc + fs - 1) / fs);
+    hipLaunchKernelGGL(k_csdm_gemm, dim3(nb, nblk * nblk, slices), dim3(256), 0, c.stream, Xt, nch, mc, nblk, G, fs);
     return 0;
 }
 

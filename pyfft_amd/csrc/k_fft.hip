@@ -44,19 +44,22 @@ int launch_xcorr(LaunchCtx c, const float *x1, const float *x2, int64_t n, const
 }
 
 int launch_moments(LaunchCtx c, const void *x, bool cplx, int64_t n, int mode, double *partial, double *out_d,
-                   float *trend_f) {
+                   float *trend_f, int nsignals, int64_t x_cs) {
     int64_t nb = (n + 256 * 16 - 1) / (256 * 16);
-    if (nb > 4096) nb = 4096;
+    const int64_t cap = nsignals > 1 ? (4096 / nsignals < 8 ? 8 : 4096 / nsignals) : 4096;   // partial scratch: 4096 records
+    if (nb > cap) nb = cap;
     if (nb < 1) nb = 1;
+    if ((int64_t)nsignals * nb > 4096) return -1;
     const bool lin = mode == 2;
+    const dim3 grid((unsigned)nb, (unsigned)nsignals);
     if (cplx) {
-        if (lin) hipLaunchKernelGGL((k_moments_partial<true, true>), dim3((int)nb), dim3(256), 0, c.stream, x, n, partial);
-        else hipLaunchKernelGGL((k_moments_partial<true, false>), dim3((int)nb), dim3(256), 0, c.stream, x, n, partial);
+        if (lin) hipLaunchKernelGGL((k_moments_partial<true, true>), grid, dim3(256), 0, c.stream, x, n, partial, x_cs);
+        else hipLaunchKernelGGL((k_moments_partial<true, false>), grid, dim3(256), 0, c.stream, x, n, partial, x_cs);
     } else {
-        if (lin) hipLaunchKernelGGL((k_moments_partial<false, true>), dim3((int)nb), dim3(256), 0, c.stream, x, n, partial);
-        else hipLaunchKernelGGL((k_moments_partial<false, false>), dim3((int)nb), dim3(256), 0, c.stream, x, n, partial);
+        if (lin) hipLaunchKernelGGL((k_moments_partial<false, true>), grid, dim3(256), 0, c.stream, x, n, partial, x_cs);
+        else hipLaunchKernelGGL((k_moments_partial<false, false>), grid, dim3(256), 0, c.stream, x, n, partial, x_cs);
     }
-    hipLaunchKernelGGL(k_moments_finish, dim3(1), dim3(256), 0, c.stream, partial, (int)nb, n, mode, out_d, trend_f);
+    hipLaunchKernelGGL(k_moments_finish, dim3(nsignals), dim3(256), 0, c.stream, partial, (int)nb, n, mode, out_d, trend_f);
     return 0;
 }
 

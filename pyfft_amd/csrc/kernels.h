@@ -933,18 +933,22 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
 // Real input STFT, two frames per transform: z = f_g + i f_{g+1};  X_g = (Z[k] + conj Z[n-k]) / 2,
 // X_{g+1} = (Z[k] - conj Z[n-k]) / (2i).  The mirror comes from one more LDS exchange (linear image, reversed read).
 // Power-of-two n only (mirror index by masking); the other lengths use k_stft.
+// blockIdx.y = channel: x += y*x_cs samples, out += y*out_cs elements, trend += 4*y (pseg only for one channel)
 template <int N, bool LIN>
 __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restrict__ x, const float *__restrict__ win,
                                                            int hop, int64_t nframes, int64_t ppg,
                                                            const float *__restrict__ trend, XfTables tb, int sided,
                                                            float amp, int out_power, void *__restrict__ out,
-                                                           double *__restrict__ pseg) {
+                                                           double *__restrict__ pseg, int64_t x_cs, int64_t out_cs) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
     float w[C::R];
 #pragma unroll
     for (int t = 0; t < C::R; ++t) w[t] = win[tid + C::T * t];
-    const Trend tr = load_trend(trend);
+    x += (int64_t)blockIdx.y * x_cs;
+    if (out_power) out = reinterpret_cast<float *>(out) + (int64_t)blockIdx.y * out_cs;
+    else out = reinterpret_cast<cf *>(out) + (int64_t)blockIdx.y * out_cs;
+    const Trend tr = load_trend(trend + 4 * blockIdx.y);
     const int nb = nbins_of(n, sided);
     const int64_t npairs = (nframes + 1) / 2;
     const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
@@ -1137,8 +1141,9 @@ static __global__ void k_csdm_transpose(const cf *__restrict__ Xs, cf *__restric
 
 #define SP_CM_B 64      // channel block
 #define SP_CM_F 32      // frames staged per step
+// blockIdx.z = frame slice [z*fs, (z+1)*fs) of the chunk; with more than one slice the float64 adds are atomic
 static __global__ __launch_bounds__(256) void k_csdm_gemm(const cf *__restrict__ Xt, int nch, int64_t mc, int nblk,
-                                                           double *__restrict__ G /*[nb][nch][nch][2]*/) {
+                                                           double *__restrict__ G /*[nb][nch][nch][2]*/, int64_t fs) {
     __shared__ cf Ai[SP_CM_B][SP_CM_F + 1], Aj[SP_CM_B][SP_CM_F + 1];
     const int k = blockIdx.x;
     const int bi = blockIdx.y / nblk, bj = blockIdx.y % nblk;
@@ -1150,14 +1155,15 @@ static __global__ __launch_bounds__(256) void k_csdm_gemm(const cf *__restrict__
 #pragma unroll
         for (int v = 0; v < 4; ++v) acc[u][v] = mk(0.f, 0.f);
     const cf *base = Xt + (int64_t)k * nch * mc;
-    for (int64_t g0 = 0; g0 < mc; g0 += SP_CM_F) {
+    const int64_t gbeg = (int64_t)blockIdx.z * fs, gend = gbeg + fs < mc ? gbeg + fs : mc;
+    for (int64_t g0 = gbeg; g0 < gend; g0 += SP_CM_F) {
         // stage 64 channels x 32 frames of both blocks (rows beyond nch / frames beyond mc are zero)
         for (int e = threadIdx.x; e < SP_CM_B * SP_CM_F; e += 256) {
             const int row = e / SP_CM_F, f = e % SP_CM_F;
             const int64_t gg = g0 + f;
             const int ci = bi * SP_CM_B + row, cj = bj * SP_CM_B + row;
-            Ai[row][f] = (ci < nch && gg < mc) ? base[(int64_t)ci * mc + gg] : mk(0.f, 0.f);
-            Aj[row][f] = (cj < nch && gg < mc) ? base[(int64_t)cj * mc + gg] : mk(0.f, 0.f);
+            Ai[row][f] = (ci < nch && gg < gend) ? base[(int64_t)ci * mc + gg] : mk(0.f, 0.f);
+            Aj[row][f] = (cj < nch && gg < gend) ? base[(int64_t)cj * mc + gg] : mk(0.f, 0.f);
         }
         __syncthreads();
 #pragma unroll 4
@@ -1185,8 +1191,13 @@ static __global__ __launch_bounds__(256) void k_csdm_gemm(const cf *__restrict__
             const int i = bi * SP_CM_B + 4 * ti + u, j = bj * SP_CM_B + 4 * tj + v;
             if (i < nch && j < nch) {
                 double *p = G + (((int64_t)k * nch + i) * nch + j) * 2;
-                p[0] += (double)acc[u][v].x;
-                p[1] += (double)acc[u][v].y;
+                if (gridDim.z > 1) {
+                    atomicAdd(p, (double)acc[u][v].x);
+                    atomicAdd(p + 1, (double)acc[u][v].y);
+                } else {
+                    p[0] += (double)acc[u][v].x;
+                    p[1] += (double)acc[u][v].y;
+                }
             }
         }
 }
@@ -1365,13 +1376,16 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_xcorr(const float *__restrict_
 // partial[block][8] = sum re, sum im, sum |x|^2, sum i*re, sum i*im, 0, 0, 0   (i = sample index)
 // ------------------------------------------------------------------------------------------
 #define SP_MOM 5
+// blockIdx.y = signal number: samples start at x + y*x_cs, partials at partial + y*gridDim.x*8
 template <bool CPLX, bool LIN>
 __global__ __launch_bounds__(256) void k_moments_partial(const void *__restrict__ x, int64_t n,
-                                                          double *__restrict__ partial) {
+                                                          double *__restrict__ partial, int64_t x_cs) {
     double s[SP_MOM] = {0, 0, 0, 0, 0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t off = (int64_t)blockIdx.y * x_cs;
+    partial += (int64_t)blockIdx.y * gridDim.x * 8;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const cf a = load_sample(x, i, CPLX);
+        const cf a = load_sample(x, off + i, CPLX);
         s[0] += a.x;
         s[1] += a.y;
         s[2] += (double)a.x * a.x + (double)a.y * a.y;
@@ -1397,10 +1411,14 @@ __global__ __launch_bounds__(256) void k_moments_partial(const void *__restrict_
 
 // one block of 256.  out_d[0..1] = mean, out_d[2] = sum|x|^2, out_d[3..4] = sum i*x.
 // trend_f[4] (optional): mode 1 -> (mean, 0 slope); mode 2 -> least-squares line m + s*i
+// blockIdx.x = signal number (partials / outputs strided accordingly)
 static __global__ __launch_bounds__(256) void k_moments_finish(const double *__restrict__ partial, int nblocks, int64_t n,
                                                          int mode, double *__restrict__ out_d,
                                                          float *__restrict__ trend_f) {
     __shared__ double sh[SP_MOM][256];
+    partial += (int64_t)blockIdx.x * nblocks * 8;
+    if (out_d) out_d += (int64_t)blockIdx.x * 8;
+    if (trend_f) trend_f += (int64_t)blockIdx.x * 4;
     double s[SP_MOM] = {0, 0, 0, 0, 0};
     for (int b = threadIdx.x; b < nblocks; b += 256) {
 #pragma unroll

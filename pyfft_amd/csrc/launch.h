@@ -76,7 +76,8 @@ int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &
 int launch_welch_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
                     const Xf &xf, float *partial, const RunPart &rp);
 int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
-                   const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg);
+                   const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg,
+                   int nchan = 1, int64_t x_cs = 0, int64_t out_cs = 0);
 int launch_csd(LaunchCtx c, const void *x, const void *y, bool cplx, int nch, int64_t y_ld, const float *win, int hop,
                int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,
                const RunPart &rp);
@@ -97,7 +98,7 @@ int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int6
 int launch_fftfilt(LaunchCtx c, const float *x, int64_t n, int ntaps, const cf *Hs, const Xf &xf, float *y);
 int launch_xcorr(LaunchCtx c, const float *x1, const float *x2, int64_t n, const double *mom, const Xf &xf, float *co);
 int launch_moments(LaunchCtx c, const void *x, bool cplx, int64_t n, int mode, double *partial_scratch, double *out_d,
-                   float *trend_f);
+                   float *trend_f, int nsignals = 1, int64_t x_cs = 0);
 int launch_transpose(LaunchCtx c, const void *in, void *out, int64_t rows, int64_t cols, int elem_bytes);
 
 // dispatch over the transform: MACRO(XTYPE) with XTYPE = XfPow2<L> or XfBlue<L>

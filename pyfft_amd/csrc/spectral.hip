@@ -901,8 +901,16 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
     if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
     TrendBuf tb;
     if (get_trendbuf(2 * nch, &tb)) return -1;           // second half: trends re-based to the current frame chunk
-    for (int c = 0; c < nch; ++c)
-        if (set_trend(tb, c, xd + (size_t)x_ld * (size_t)c, false, nsig, detrend, 0, 0)) return -1;
+    if (detrend == 0) {
+        HIPCHK(hipMemsetAsync(tb.f, 0, sizeof(float) * 4 * (size_t)nch, g.stream));
+    } else if (nch <= 512) {
+        double *scr = moments_scratch();                 // all channels in one launch
+        if (!scr) return -1;
+        LAUNCHCHK(launch_moments(lc(), xd, false, nsig, detrend, scr, tb.d, tb.f, nch, x_ld));
+    } else {
+        for (int c = 0; c < nch; ++c)
+            if (set_trend(tb, c, xd + (size_t)x_ld * (size_t)c, false, nsig, detrend, 0, 0)) return -1;
+    }
     const size_t gbytes = sizeof(double) * 2 * (size_t)nb * (size_t)nch * (size_t)nch;
     double *G = g_out;
     if (!mem) {
@@ -910,8 +918,8 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
         G = (double *)g.cmG.p;
     }
     HIPCHK(hipMemsetAsync(G, 0, gbytes, g.stream));
-    // frames are processed in chunks so the two spectra buffers stay <= 2 GiB each (and float sums stay short)
-    int64_t mc = ((int64_t)1 << 28) / ((int64_t)nch * nb);
+    // frames are processed in chunks so the two spectra buffers stay <= 8 GiB each (and float sums stay short)
+    int64_t mc = ((int64_t)1 << 30) / ((int64_t)nch * nb);
     if (mc > 8192) mc = 8192;
     if (mc < 32) mc = 32;
     mc &= ~(int64_t)31;
@@ -921,13 +929,21 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
     cf *Xs = (cf *)g.cmS.p, *Xt = (cf *)g.cmT.p;
     for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
         const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
-        const RunPart rp = run_partition(xf.L, m, g.ncu, 2);
         hipLaunchKernelGGL(k_trend_shift, dim3((nch + 63) / 64), dim3(64), 0, g.stream, tb.f, tb.f + 4 * nch, nch,
                            (double)f0 * (double)hop);
-        for (int c = 0; c < nch; ++c)
-            LAUNCHCHK(launch_stft(lc(), xd + (size_t)x_ld * (size_t)c + (size_t)f0 * (size_t)hop, false, (const float *)win_d,
-                                  hop, m, tb.f + 4 * (nch + c), detrend == 2, xf, rp, SP_SIDED_HALF, 1.f, 0,
-                                  Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
+        if (!xf.blue && xf.L >= 32 && m >= 2 && nch <= 65535) {
+            // all channels in one grid, two real frames per transform
+            const RunPart rp = run_partition(xf.L, (m + 1) / 2, g.ncu, 1);
+            LAUNCHCHK(launch_stft_rp(lc(), xd + (size_t)f0 * (size_t)hop, (const float *)win_d, hop, m, tb.f + 4 * nch,
+                                     detrend == 2, xf, rp, SP_SIDED_HALF, 1.f, 0, Xs, nullptr, nch, x_ld,
+                                     (int64_t)m * nb));
+        } else {
+            const RunPart rp = run_partition(xf.L, m, g.ncu, 2);
+            for (int c = 0; c < nch; ++c)
+                LAUNCHCHK(launch_stft(lc(), xd + (size_t)x_ld * (size_t)c + (size_t)f0 * (size_t)hop, false,
+                                      (const float *)win_d, hop, m, tb.f + 4 * (nch + c), detrend == 2, xf, rp, SP_SIDED_HALF,
+                                      1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
+        }
         LAUNCHCHK(launch_csdm_transpose(lc(), Xs, Xt, nch, m, nb));
         LAUNCHCHK(launch_csdm_gemm(lc(), Xt, nch, m, nb, G));
     }
