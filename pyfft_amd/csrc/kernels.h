@@ -353,7 +353,11 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
             xf.fwd(v, lds, tid, N);
         }
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) acc[t] = UNI ? acc[t] + cnorm(v[t]) : acc[t] + keep * cnorm(v[t]);
+        for (int t = 0; t < C::R; ++t) {
+            // two chained FMAs per bin (`acc + (x*x + y*y)` would be mul + fma + add)
+            if (UNI) acc[t] = fmaf(v[t].y, v[t].y, fmaf(v[t].x, v[t].x, acc[t]));
+            else acc[t] += keep * cnorm(v[t]);
+        }
         // advance one hop: rename registers, detrend the samples that just arrived
 #pragma unroll
         for (int t = 0; t < KEEP; ++t) raw[t] = raw[t + SHIFT];
@@ -466,45 +470,9 @@ static __global__ __launch_bounds__(1024) void k_op_total(const void *__restrict
     }
 }
 
-// dlt = mean - mu0, with mean either given (mean_in != null: global mean from the caller) or tot/nmean
-static __global__ void k_op_delta(const double *__restrict__ tot, int64_t nmean, const double *__restrict__ mean_in,
-                                  const float *__restrict__ trend, double *__restrict__ dlt) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (mean_in) {
-            dlt[0] = mean_in[0] - (double)trend[0];
-            dlt[1] = mean_in[1] - (double)trend[1];
-        } else {
-            dlt[0] = tot[0] / (double)nmean;
-            dlt[1] = tot[1] / (double)nmean;
-        }
-    }
-}
-
-// cw[n] = w[n] * c[n],  c[qH+j] = Sl[j] + sum_{b=q}^{r-2} xb[j] - sum_{b=M+q}^{M+r-2} xb[j]   (xb = x - mu0, block b)
-template <bool CPLX>
-static __global__ void k_op_cw(const void *__restrict__ x, const float *__restrict__ trend, const float *__restrict__ win,
-                               const double *__restrict__ Sl, int N, int H, int r, int64_t M, cf *__restrict__ cw) {
-    const int nidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (nidx >= N) return;
-    const cf mu = mk(trend[0], trend[1]);
-    const int q = nidx / H, j = nidx % H;
-    double a = Sl[2 * j], b = Sl[2 * j + 1];
-    for (int bb = q; bb <= r - 2; ++bb) {
-        const cf v = load_sample(x, (int64_t)bb * H + j, CPLX) - mu;
-        a += v.x;
-        b += v.y;
-    }
-    for (int64_t bb = M + q; bb <= M + r - 2; ++bb) {
-        const cf v = load_sample(x, bb * H + j, CPLX) - mu;
-        a -= v.x;
-        b -= v.y;
-    }
-    const double wn = (double)win[nidx];
-    cw[nidx] = mk((float)(wn * a), (float)(wn * b));
-}
-
-// one workgroup: c[n] from the block sums, B = FFT(w c), then the combine below -- replaces k_op_cw + k_fft_c2c +
-// k_op_combine (three launches) for every N the carry kernel supports.  mean_in != null overrides the local delta.
+// one workgroup: c[n] = sum_g x_g[n] rebuilt from the block sums and the few edge blocks, B = FFT(w c) = sum_g X_g,
+// then out[slot] = scale * doubling * (A[k] - 2 Re(conj(d W[k]) B[k]) + M |d W[k]|^2) with d = mean - mu0.
+// mean_in != null (the caller's global mean) overrides the shard's own delta.
 template <int N, bool CPLX>
 static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *__restrict__ x, const float *__restrict__ trend,
                                                                     const float *__restrict__ win,
@@ -558,22 +526,6 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
             out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
         }
     }
-}
-
-// out[slot] = scale * doubling * (A[k] - 2 Re(conj(d Wf[k]) B[k]) + M |d Wf[k]|^2)
-static __global__ void k_op_combine(const double *__restrict__ A, const cf *__restrict__ B, const cf *__restrict__ Wf,
-                                    const double *__restrict__ dlt, int N, int64_t M, int sided, double scale,
-                                    double *__restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
-    const int slot = bin_slot(k, N, sided);
-    if (slot < 0) return;
-    const double dr = dlt[0], di = dlt[1];
-    const double wr = Wf[k].x, wi = Wf[k].y;
-    const double er = dr * wr - di * wi, ei = dr * wi + di * wr;       // d * Wf[k]
-    const double br = B[k].x, bi = B[k].y;
-    const double p = A[k] - 2.0 * (er * br + ei * bi) + (double)M * (er * er + ei * ei);
-    out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
 }
 
 // mean estimate mu0: 64 contiguous runs of <= 1024 samples spread over the whole signal (robust to drift, and each
@@ -1141,10 +1093,13 @@ static __global__ void k_csdm_transpose(const cf *__restrict__ Xs, cf *__restric
 
 #define SP_CM_B 64      // channel block
 #define SP_CM_F 32      // frames staged per step
-// blockIdx.z = frame slice [z*fs, (z+1)*fs) of the chunk; with more than one slice the float64 adds are atomic
+#define SP_CM_P 66      // LDS pitch (complex) of one staged frame: 16-byte aligned rows, reads of 4 consecutive
+                        // channels per lane are two conflict-free ds_read_b128, staging writes are 2-way at worst
+// blockIdx.z = frame slice [z*fs, (z+1)*fs) of the chunk; with more than one slice the float64 adds are atomic.
+// Staged image: A[f][channel] (channel fastest).  Global loads for step s+1 are issued before the FMAs of step s.
 static __global__ __launch_bounds__(256) void k_csdm_gemm(const cf *__restrict__ Xt, int nch, int64_t mc, int nblk,
                                                            double *__restrict__ G /*[nb][nch][nch][2]*/, int64_t fs) {
-    __shared__ cf Ai[SP_CM_B][SP_CM_F + 1], Aj[SP_CM_B][SP_CM_F + 1];
+    __shared__ __attribute__((aligned(16))) cf Ai[SP_CM_F][SP_CM_P], Aj[SP_CM_F][SP_CM_P];
     const int k = blockIdx.x;
     const int bi = blockIdx.y / nblk, bj = blockIdx.y % nblk;
     if (bj < bi) return;                                   // Hermitian: the mirror block is filled at the end
@@ -1156,33 +1111,55 @@ static __global__ __launch_bounds__(256) void k_csdm_gemm(const cf *__restrict__
         for (int v = 0; v < 4; ++v) acc[u][v] = mk(0.f, 0.f);
     const cf *base = Xt + (int64_t)k * nch * mc;
     const int64_t gbeg = (int64_t)blockIdx.z * fs, gend = gbeg + fs < mc ? gbeg + fs : mc;
-    for (int64_t g0 = gbeg; g0 < gend; g0 += SP_CM_F) {
-        // stage 64 channels x 32 frames of both blocks (rows beyond nch / frames beyond mc are zero)
-        for (int e = threadIdx.x; e < SP_CM_B * SP_CM_F; e += 256) {
+    // staging assignment: element e = threadIdx.x + 256*q  ->  (row = e / 32, f = e % 32): a wave reads 2 rows x 32
+    // consecutive frames (256 B each) from HBM
+    constexpr int NQ = SP_CM_B * SP_CM_F / 256;            // 8
+    cf ri[NQ], rj[NQ];
+    auto fetch = [&](int64_t g0) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = threadIdx.x + 256 * q;
             const int row = e / SP_CM_F, f = e % SP_CM_F;
             const int64_t gg = g0 + f;
             const int ci = bi * SP_CM_B + row, cj = bj * SP_CM_B + row;
-            Ai[row][f] = (ci < nch && gg < gend) ? base[(int64_t)ci * mc + gg] : mk(0.f, 0.f);
-            Aj[row][f] = (cj < nch && gg < gend) ? base[(int64_t)cj * mc + gg] : mk(0.f, 0.f);
+            const bool oki = ci < nch && gg < gend, okj = cj < nch && gg < gend;
+            const cf a = base[(int64_t)(oki ? ci : 0) * mc + (oki ? gg : gbeg)];
+            const cf b = base[(int64_t)(okj ? cj : 0) * mc + (okj ? gg : gbeg)];
+            ri[q] = oki ? a : mk(0.f, 0.f);
+            rj[q] = okj ? b : mk(0.f, 0.f);
+        }
+    };
+    if (gbeg < gend) fetch(gbeg);
+    for (int64_t g0 = gbeg; g0 < gend; g0 += SP_CM_F) {
+        __syncthreads();                                   // previous step's readers are done
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            Ai[e % SP_CM_F][e / SP_CM_F] = ri[q];
+            Aj[e % SP_CM_F][e / SP_CM_F] = rj[q];
         }
         __syncthreads();
+        if (g0 + SP_CM_F < gend) fetch(g0 + SP_CM_F);      // in flight during the FMAs below
 #pragma unroll 4
         for (int f = 0; f < SP_CM_F; ++f) {
             cf a[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[u] = Ai[4 * ti + u][f];
-                b[u] = Aj[4 * tj + u][f];
-            }
+            const float4 a01 = *reinterpret_cast<const float4 *>(&Ai[f][4 * ti]);
+            const float4 a23 = *reinterpret_cast<const float4 *>(&Ai[f][4 * ti + 2]);
+            const float4 b01 = *reinterpret_cast<const float4 *>(&Aj[f][4 * tj]);
+            const float4 b23 = *reinterpret_cast<const float4 *>(&Aj[f][4 * tj + 2]);
+            a[0] = mk(a01.x, a01.y); a[1] = mk(a01.z, a01.w); a[2] = mk(a23.x, a23.y); a[3] = mk(a23.z, a23.w);
+            b[0] = mk(b01.x, b01.y); b[1] = mk(b01.z, b01.w); b[2] = mk(b23.x, b23.y); b[3] = mk(b23.z, b23.w);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    acc[u][v].x += a[u].x * b[v].x + a[u].y * b[v].y;       // a conj(b)
-                    acc[u][v].y += a[u].y * b[v].x - a[u].x * b[v].y;
+                    // a conj(b) as four chained FMAs (the compiler may not re-associate `acc += p + q`)
+                    acc[u][v].x = fmaf(a[u].x, b[v].x, acc[u][v].x);
+                    acc[u][v].x = fmaf(a[u].y, b[v].y, acc[u][v].x);
+                    acc[u][v].y = fmaf(a[u].y, b[v].x, acc[u][v].y);
+                    acc[u][v].y = fmaf(-a[u].x, b[v].y, acc[u][v].y);
                 }
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -1207,7 +1184,6 @@ static __global__ void k_csdm_finish(double *__restrict__ G, int nch, int nb, do
     const int64_t total = (int64_t)nb * nch * nch;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(e % nch), i = (int)((e / nch) % nch);
-        const int64_t k = e / ((int64_t)nch * nch);
         if (j / SP_CM_B >= i / SP_CM_B) {
             G[2 * e] *= scale;
             G[2 * e + 1] *= scale;

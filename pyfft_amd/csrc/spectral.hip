@@ -106,13 +106,6 @@ struct Pending {
     double *sum_d = nullptr;
 } g_pend;
 
-__global__ void k_op_sum(const double *tot, const float *trend, int64_t nmean, double *sum_out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        sum_out[0] = tot[0] + (double)nmean * (double)trend[0];
-        sum_out[1] = tot[1] + (double)nmean * (double)trend[1];
-    }
-}
-
 struct ProfScope {   // brackets one kernel launch with HIP events on the launch stream when profiling is on
     bool on;
     ProfScope() : on(g.profile) {
