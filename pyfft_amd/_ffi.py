@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libspectral.so")
+LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(_HERE, "lib", "libspectral.so")   # SP_LIB_PATH: diagnostic builds
 
 DTYPE_F32, DTYPE_C64 = 0, 1
 SIDED_ONE, SIDED_TWO, SIDED_RAW, SIDED_HALF = 1, 2, 3, 4

@@ -98,7 +98,13 @@ template <bool INV> __device__ __forceinline__ void dft16(cf (&x)[16]) {
 #undef SP_SWAP
 }
 
+// SP_ABLATE (diagnostic builds only, results wrong): bit 0 = skip the radix-16 butterflies, bit 1 = skip the LDS
+// exchanges (and their barriers), bit 2 = skip the inter-pass twiddle multiplies
+#ifndef SP_ABLATE
+#define SP_ABLATE 0
+#endif
 template <int RDX, bool INV> __device__ __forceinline__ void dftR(cf (&x)[RDX]) {
+    if (RDX == 16 && (SP_ABLATE & 1)) return;
     if constexpr (RDX == 2) dft2<INV>(x[0], x[1]);
     else if constexpr (RDX == 4) dft4<INV>(x[0], x[1], x[2], x[3]);
     else if constexpr (RDX == 8) dft8<INV>(x);
@@ -130,23 +136,41 @@ template <int N> struct FftPlan {
 };
 
 // ---- the workgroup FFT ------------------------------------------------------------------
-template <int N, bool INV> struct WgFft {
+// TWL: the twiddles of pass 1 (radix 16 after one radix-16 pass: W_256^{(q%16) s}, only 16 x 15 distinct values per
+// workgroup) are read from a small LDS table `ltw[(s-1)*16 + q%16]` each frame instead of living in 30 VGPRs.
+template <int N, bool INV, bool TWL = false> struct WgFft {
     using PL = FftPlan<N>;
     static constexpr int R = PL::R, T = PL::T, NP = PL::NP;
+    static constexpr bool USE_TWL = TWL && NP >= 2 && PL::radix(1) == 16 && PL::radix(0) == 16;
+    static constexpr int LTW_ELEMS = USE_TWL ? 15 * 16 : 0;
     cf tw[PL::NTW > 0 ? PL::NTW : 1];
+    const cf *ltw = nullptr;
 
     // table[m] = exp(-2 pi i m / N), m = 0..N-1
     __device__ __forceinline__ void load_twiddles(const cf *__restrict__ table, int tid) { load_tw<1>(table, tid); }
 
+    // fill the LDS table (every thread of the workgroup calls this once, then a barrier)
+    __device__ __forceinline__ void fill_lds_twiddles(const cf *__restrict__ table, cf *lds_table, int wg_tid, int wg_size) {
+        if constexpr (USE_TWL) {
+            for (int e = wg_tid; e < 15 * 16; e += wg_size) {
+                const int s = e / 16 + 1, j = e % 16;
+                lds_table[e] = table[(j * s) * (N / 256)];
+            }
+            ltw = lds_table;
+        }
+    }
+
     template <int P> __device__ __forceinline__ void load_tw(const cf *__restrict__ table, int tid) {
         if constexpr (P < NP) {
             constexpr int r = PL::radix(P), NS = PL::ns(P), NB = R / r, OFF = PL::ntw_before(P);
+            if constexpr (!(USE_TWL && P == 1)) {
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int q = tid + T * u;
-                const int e = (q % NS) * (N / (NS * r));
+                for (int u = 0; u < NB; ++u) {
+                    const int q = tid + T * u;
+                    const int e = (q % NS) * (N / (NS * r));
 #pragma unroll
-                for (int s = 1; s < r; ++s) tw[OFF + u * (r - 1) + (s - 1)] = table[e * s];
+                    for (int s = 1; s < r; ++s) tw[OFF + u * (r - 1) + (s - 1)] = table[e * s];
+                }
             }
             load_tw<P + 1>(table, tid);
         }
@@ -168,18 +192,24 @@ template <int N, bool INV> struct WgFft {
         constexpr int r = PL::radix(P), NS = PL::ns(P), NB = R / r, OFF = PL::ntw_before(P);
         constexpr bool LAST = (P == NP - 1);
         cf *lds = (P & 1) ? lds1 : lds0;
-        if constexpr (!LAST && SINGLE) __syncthreads();   // previous readers of this image are done
+        if constexpr (!LAST && SINGLE && !(SP_ABLATE & 2)) __syncthreads();   // previous readers of this image are done
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             cf x[r];
 #pragma unroll
             for (int s = 0; s < r; ++s) x[s] = v[u + s * NB];
-            if constexpr (P > 0) {
+            if constexpr (P > 0 && !(SP_ABLATE & 4)) {
+                if constexpr (USE_TWL && P == 1) {
+                    const int j = (tid + T * u) & 15;
 #pragma unroll
-                for (int s = 1; s < r; ++s) x[s] = twm<INV>(x[s], tw[OFF + u * (r - 1) + (s - 1)]);
+                    for (int s = 1; s < r; ++s) x[s] = twm<INV>(x[s], ltw[(s - 1) * 16 + j]);
+                } else {
+#pragma unroll
+                    for (int s = 1; s < r; ++s) x[s] = twm<INV>(x[s], tw[OFF + u * (r - 1) + (s - 1)]);
+                }
             }
             dftR<r, INV>(x);
-            if constexpr (LAST) {
+            if constexpr (LAST || (SP_ABLATE & 2)) {
 #pragma unroll
                 for (int s = 0; s < r; ++s) v[u + s * NB] = x[s];
             } else {
@@ -189,7 +219,9 @@ template <int N, bool INV> struct WgFft {
                 for (int s = 0; s < r; ++s) lds[phys<P>(base + s * NS)] = x[s];
             }
         }
-        if constexpr (!LAST) {
+        if constexpr (!LAST && (SP_ABLATE & 2)) {
+            pass<P + 1, SINGLE>(v, lds0, lds1, tid);
+        } else if constexpr (!LAST) {
             __syncthreads();
             if constexpr (P == 0 && (T % 16) == 0 && PL::radix(0) == 16) {
                 // i = tid + T*t  ->  (i%16)*PITCH1 + i/16 = (tid%16)*PITCH1 + tid/16 + (T/16)*t

@@ -46,6 +46,21 @@ template <int N> struct XfPow2 {
     __device__ __forceinline__ void fwd2(cf (&v)[C::R], cf *lds_a, cf *lds_b, int tid) const { f.template run<false>(v, lds_a, lds_b, tid); }
 };
 
+// same transform, second-pass twiddles in an LDS table (frees 30 VGPRs; the carry kernel's third wave per SIMD)
+template <int N> struct XfPow2L {
+    static constexpr int L = N;
+    static constexpr bool EXACT = true;
+    using C = WgCfg<N>;
+    WgFft<N, false, true> f;
+    static constexpr int LTW = WgFft<N, false, true>::LTW_ELEMS;
+    __device__ __forceinline__ void init(const XfTables &tb, int tid, cf *lds_table, int wg_tid, int wg_size) {
+        f.load_twiddles(tb.tw, tid);
+        f.fill_lds_twiddles(tb.tw, lds_table, wg_tid, wg_size);
+    }
+    __device__ __forceinline__ void fwd(cf (&v)[C::R], cf *lds, int tid, int) const { f.template run<true>(v, lds, lds, tid); }
+    __device__ __forceinline__ void fwd2(cf (&v)[C::R], cf *lds_a, cf *lds_b, int tid) const { f.template run<false>(v, lds_a, lds_b, tid); }
+};
+
 template <int L_> struct XfBlue {
     static constexpr int L = L_;
     static constexpr bool EXACT = false;
@@ -287,14 +302,34 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_rp(const float *__restrict__
 #ifndef SP_CARRY_NBUF
 #define SP_CARRY_NBUF 1
 #endif
+// second-pass twiddles of the carry kernel from an LDS table (1: 164 VGPRs, 3 waves/SIMD, no spills) or from
+// registers (0: 173-207 VGPRs, 2 waves/SIMD).  Measured equal (0.66 vs 0.65 ms): the kernel is VALU-issue bound,
+// not occupancy bound (ablation table), so the variant with fewer LDS instructions is the default.
+#ifndef SP_CARRY_TWL
+#define SP_CARRY_TWL 0
+#endif
 // (no min-waves hint: capping at 168 VGPRs makes hipcc spill the window registers and reload them inside the
 //  frame loop behind vmcnt(0) waits, which also drains the prefetch loads -- measured 2x slower)
 template <int N, bool CPLX, int SHIFT, bool ONEPASS>
 __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
     const void *__restrict__ x, const float *__restrict__ win, int64_t nframes, int64_t fpg,
     const float *__restrict__ trend, XfTables tb, float *__restrict__ partial, cf *__restrict__ spartial) {
+#if SP_CARRY_TWL
+    using X = XfPow2L<N>;
+    using C = typename X::C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *smem = reinterpret_cast<cf *>(smem_raw);
+    const int grp = C::FPW == 1 ? 0 : (int)threadIdx.x / C::T;
+    const int tid = C::FPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % C::T;
+    cf *lds = smem + grp * C::LDS_PER;
+    X xf;
+    xf.init(tb, tid, smem + SP_CARRY_NBUF * C::FPW * C::LDS_PER, (int)threadIdx.x, C::WG);
+    __syncthreads();
+    const int n = N;
+#else
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
+#endif
     (void)n;
     static_assert(SHIFT >= 1 && SHIFT <= C::R, "hop must be 1..R register slots");
     constexpr int KEEP = C::R - SHIFT;
@@ -329,14 +364,6 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
     for (int64_t i = 0; i < trips; ++i) {
         const int64_t g = g0 + i;
         const float keep = (UNI || g < nframes) ? 1.f : 0.f;
-        // prefetch the SHIFT new slots of frame g+1 (clamped at the end of the signal; unused then)
-        cf nx[SHIFT];
-        {
-            const int64_t gn = g + 1 < nframes ? g + 1 : last;
-            const int64_t base = gn * hop + tid + (int64_t)C::T * KEEP;
-#pragma unroll
-            for (int s = 0; s < SHIFT; ++s) nx[s] = load_sample(x, base + C::T * s, CPLX);
-        }
         if (ONEPASS) {
 #pragma unroll
             for (int s = 0; s < SHIFT; ++s) sacc[s] = UNI ? sacc[s] + raw[KEEP + s] : sacc[s] + keep * raw[KEEP + s];
@@ -344,6 +371,15 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
         cf v[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = w[t] * raw[t];
+        // prefetch the SHIFT new slots of frame g+1 (clamped at the end of the signal; unused then).  Issued after
+        // v is formed so that the incoming samples can take over the registers of the slots that just died.
+        cf nx[SHIFT];
+        {
+            const int64_t gn = g + 1 < nframes ? g + 1 : last;
+            const int64_t base = gn * hop + tid + (int64_t)C::T * KEEP;
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) nx[s] = load_sample(x, base + C::T * s, CPLX);
+        }
         if (SP_CARRY_NBUF == 2) {
             // ping-pong exchange images: with an odd number of exchanges per transform the roles swap every frame
             cf *lds_b = lds + C::FPW * C::LDS_PER;
