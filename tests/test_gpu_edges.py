@@ -1,0 +1,117 @@
+"""Edge cases through the C ABI and the drop-in layer: degenerate sizes, a single segment (nwins >= nsig), ragged
+tails, maximum workgroup sizes, argument errors.  GPU."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import cpu_ref as O
+
+
+@pytest.fixture(scope="module")
+def P():
+    import pyfft_amd
+    from pyfft_amd import _ffi
+    _ffi.init()
+    return pyfft_amd
+
+
+def test_tiny_and_degenerate_transforms(P):
+    E = P.engine
+    assert np.allclose(E.fft(np.array([3.0 + 1j], dtype=np.complex64)), [3.0 + 1j])            # n = 1
+    x = np.array([[1, 2], [3, 4]], dtype=np.complex64)
+    np.testing.assert_allclose(E.fft(x), np.fft.fft(x), atol=1e-6)                              # n = 2
+    assert E.fft(np.zeros((0, 8), dtype=np.complex64)).shape == (0, 8)                          # empty batch
+    z = np.zeros(64, dtype=np.complex64)
+    assert np.all(E.fft(z) == 0)
+    big = np.full(256, 1e30, dtype=np.float32)                                                  # no overflow to inf/nan
+    assert np.all(np.isfinite(E.fft(big * 1e-3)))
+
+
+def test_single_segment_welch_and_nwins_ge_nsig(P):
+    """fft_pwelch with Navr=1: nwins collapses to nsig (fft_analysis.py:214-216), any length up to the workgroup limit"""
+    rng = np.random.default_rng(2)
+    for n in (100, 1000, 4096, 3001):
+        t = np.arange(n + 1) / 100.0
+        x = rng.standard_normal(n + 1)
+        y = rng.standard_normal(n + 1)
+        freq, Pxy, Pxx, Pyy, Cxy, phi, info = P.fft_pwelch(t, x, y, [t[0], t[-2]], Navr=1, windowoverlap=0.0,
+                                                          windowfunction="box", plotit=False)
+        r = O.fft_pwelch(t, x, y, tbounds=[t[0], t[-2]], Navr=1, windowoverlap=0.0, windowfunction="box")
+        assert info.Navr == 1 == r[6]["Navr"] and info.nwins == r[6]["nwins"] == n
+        np.testing.assert_allclose(Pxx, r[2], rtol=3e-4, atol=2e-6 * np.abs(r[2]).max())
+        np.testing.assert_allclose(Pxy, r[1], rtol=3e-4, atol=2e-6 * np.abs(r[1]).max())
+        # one segment: coherence is exactly 1 in magnitude
+        assert np.allclose(np.abs(Cxy[1:-1]), 1.0, atol=1e-3)
+
+
+def test_limits_raise_cleanly(P):
+    E = P.engine
+    Err = P._ffi.SpectralError
+    x = np.zeros(40000, dtype=np.float32)
+    with pytest.raises(Err, match="not supported"):
+        E.welch_psd(x, np.ones(16384), 8192, 2)                  # segment longer than one workgroup handles
+    with pytest.raises(Err, match="not supported"):
+        E.welch_psd(x, np.ones(5000), 2500, 3)                   # non power of two above 4096
+    with pytest.raises(Err):
+        E.welch_psd(x, np.ones(256), 128, 100000)                # frames run past the end
+    with pytest.raises(Err):
+        E.welch_psd(x, np.ones(256), 0, 4)                       # hop 0
+    with pytest.raises(Err):
+        E.fir_filter(np.ones(5000), x, nfft=4096)                # block shorter than 2*(taps-1)
+    with pytest.raises(Err):
+        E.hilbert_rows(np.zeros((2, 8), dtype=np.float32), 1)
+    with pytest.raises(ValueError):
+        E.xcorr_normalised(np.zeros(8), np.zeros(9))
+    # the library is still usable after errors
+    assert np.allclose(E.fft(np.ones(8, dtype=np.complex64))[0], 8.0)
+
+
+def test_maximum_workgroup_sizes(P):
+    E = P.engine
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(8192 * 5 + 17).astype(np.float32)
+    win = O.windows("Hanning", nwins=8192)
+    M = (x.size - 8192) // 4096 + 1
+    ref = O.welch_psd_stream(x, win, 8192, 4096, M, 1.0) * np.sum(win ** 2)
+    np.testing.assert_allclose(E.welch_psd(x, win, 4096, M, detrend=True, sided=E.SIDED_TWO, scale=1.0), ref, rtol=2e-4,
+                               atol=1e-6 * ref.max())
+    w2 = O.windows("Hamming", nwins=4095)                         # largest fused chirp-z: L = 8192
+    M2 = (x.size - 4095) // 1000 + 1
+    ref2 = O.welch_psd_stream(x, w2, 4095, 1000, M2, 1.0) * np.sum(w2 ** 2)
+    np.testing.assert_allclose(E.welch_psd(x, w2, 1000, M2, detrend=True, sided=E.SIDED_TWO, scale=1.0), ref2, rtol=3e-4,
+                               atol=2e-6 * ref2.max())
+    h = rng.standard_normal(4097)
+    y = E.fir_filter(h, x, nfft=8192)                             # most taps one block can take
+    assert np.max(np.abs(y - O.fftfilt(h.astype(np.float32).astype(np.float64), x.astype(np.float64)))) < 2e-4 * np.abs(y).max()
+
+
+def test_class_methods_crosscorr_and_amplitudes(P):
+    g = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "pwelch_cfg1.npz"))
+    t, x, y = g["t"], g["x"], g["y"]
+    ft = P.fftanal(t, x, y, tbounds=[t[0], t[-2]], Navr=127, windowoverlap=0.5, windowfunction="Hanning", verbose=False)
+    ft.pwelch()
+    ft.crosscorr()
+    ft.convert2amplitudes()
+    # class path conjugation X conj(Y) (fft_analysis.py:1960) = conj of the function path's Y conj(X) (:393)
+    np.testing.assert_allclose(ft.Pxy, np.conj(g["Pxy"]), rtol=3e-4, atol=2e-6 * np.abs(g["Pxy"]).max())
+    np.testing.assert_allclose(ft.Lxx, g["info_Lxx"], rtol=2e-4, atol=1e-6 * g["info_Lxx"].max())
+    np.testing.assert_allclose(ft.Rxx, g["info_Rxx"], rtol=0, atol=2e-4 * np.abs(g["info_Rxx"]).max())
+    np.testing.assert_allclose(ft.lags, g["info_lags"], rtol=1e-12)
+    # fftpwelch() == fft_pwelch
+    ft2 = P.fftanal(t, x, y, tbounds=[t[0], t[-2]], Navr=127, windowoverlap=0.5, windowfunction="Hanning", verbose=False)
+    ft2.fftpwelch()
+    np.testing.assert_allclose(ft2.Pxx, g["Pxx"], rtol=3e-4, atol=2e-6 * np.abs(g["Pxx"]).max())
+    assert ft2.fftinfo.Navr == 127 and hasattr(ft2, "Cxy2")
+    # transforms on the object
+    np.testing.assert_allclose(ft.ifft(ft.fft(x[:1024])), x[:1024], atol=1e-5 * np.abs(x).max())
+
+
+def test_hilbert_edge_shapes(P):
+    assert P.hilbert(np.array([1.0, 2.0, 3.0, 4.0])).shape == (4,)
+    z = P.hilbert(np.ones((1, 16)))                               # squeeze like the reference
+    assert z.shape == (16,)
+    np.testing.assert_allclose(P.hilbert(np.array([1.0, -1.0])), O.hilbert(np.array([1.0, -1.0])), atol=1e-6)
+    np.testing.assert_allclose(P.hilbert(np.arange(5.0)), O.hilbert(np.arange(5.0)), atol=2e-6)     # odd quirk
+    with pytest.raises(NotImplementedError):
+        P.hilbert(np.ones(8) + 1j)
