@@ -25,10 +25,31 @@ int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int6
 int launch_fftfilt(LaunchCtx c, const float *x, int64_t n, int ntaps, const cf *Hs, const Xf &xf, float *y) {
     const int64_t Lb = xf.L - (ntaps - 1);
     const int64_t npairs = ((n + Lb - 1) / Lb + 1) / 2;
-    const int blocks = strided_blocks(xf.L, npairs, c.ncu);
+    // interior pairs: both blocks and their outputs wholly inside [0, n): pair p reads [2pLb-(P-1), 2pLb+Lb+N-(P-1))
+    int64_t pi0 = 1, pi1 = 0;
+    if (npairs >= 3) {
+        // largest p with 2 p Lb - (P-1) + Lb + N <= n
+        pi1 = (n - xf.L - Lb + (ntaps - 1)) / (2 * Lb) + 1;
+        if (pi1 > npairs) pi1 = npairs;
+        if (pi1 < pi0) pi1 = pi0;
+    } else {
+        pi0 = pi1 = 0;
+    }
 #define M_(XT)                                                                                        \
-    hipLaunchKernelGGL((k_fftfilt<XT::L>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n, ntaps, \
-                       Hs, xf.tb, y);
+    if (pi1 > pi0) {                                                                                  \
+        const int blocks = strided_blocks(xf.L, pi1 - pi0, c.ncu);                                    \
+        hipLaunchKernelGGL((k_fftfilt<XT::L, false>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n, \
+                           ntaps, Hs, xf.tb, y, pi0, pi1);                                            \
+    }                                                                                                 \
+    if (pi0 > 0 || pi1 <= pi0) {                                                                      \
+        const int64_t e1 = pi1 > pi0 ? pi0 : npairs;                                                  \
+        hipLaunchKernelGGL((k_fftfilt<XT::L, true>), dim3(strided_blocks(xf.L, e1, c.ncu)), dim3(XT::C::WG),     \
+                           XT::C::lds_bytes(1), c.stream, x, n, ntaps, Hs, xf.tb, y, (int64_t)0, e1);   \
+    }                                                                                                 \
+    if (pi1 > pi0 && pi1 < npairs) {                                                                  \
+        hipLaunchKernelGGL((k_fftfilt<XT::L, true>), dim3(strided_blocks(xf.L, npairs - pi1, c.ncu)), dim3(XT::C::WG), \
+                           XT::C::lds_bytes(1), c.stream, x, n, ntaps, Hs, xf.tb, y, pi1, npairs);      \
+    }
     SP_DISPATCH_P(xf, M_)
 #undef M_
     return 0;

@@ -1284,47 +1284,83 @@ __global__ __launch_bounds__(X::C::WG) void k_hilbert(const float *__restrict__ 
 // F1  causal FIR by overlap-save; two real blocks ride in one complex transform (h real).
 // Block b yields y[b*Lb : (b+1)*Lb) from x[b*Lb-(P-1) : b*Lb+Lb), Lb = N-(P-1).
 // Hs[k] = FFT_N(h)[k] / N  (scale of the inverse folded in).
+// The kernel handles block pairs [p_begin, p_end).  EDGE=false: every pair in the range lies wholly inside the
+// signal -- no bounds predicates at all (they cost ~500 VALU ops per pair in 64-bit compares and selects);
+// EDGE=true: per-sample predicates, used for the first pair and the last few only.
+// Inputs of the next pair are loaded while the current pair is transformed.
 // ------------------------------------------------------------------------------------------
-template <int N>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_fftfilt(const float *__restrict__ x, int64_t nsamp, int ntaps,
+// (launch bound: at least 2 waves per SIMD, i.e. <= 256 VGPRs -- unbounded, hipcc takes 264 and halves occupancy)
+template <int N, bool EDGE>
+__global__ __launch_bounds__(WgCfg<N>::WG, 2) void k_fftfilt(const float *__restrict__ x, int64_t nsamp, int ntaps,
                                                            const cf *__restrict__ Hs, XfTables tb,
-                                                           float *__restrict__ y) {
+                                                           float *__restrict__ y, int64_t p_begin, int64_t p_end) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
     const int P1 = ntaps - 1;
     const int64_t Lb = N - P1;
-    const int64_t nblocks = (nsamp + Lb - 1) / Lb;
-    const int64_t npairs = (nblocks + 1) / 2;
-    cf H[C::R];
-#pragma unroll
-    for (int t = 0; t < C::R; ++t) H[t] = Hs[tid + C::T * t];
+    const int lb = (int)Lb;
     const int64_t stride = (int64_t)gridDim.x * C::FPW;
-    for (int64_t p0 = (int64_t)blockIdx.x * C::FPW; p0 < npairs; p0 += stride) {
+    auto fetch = [&](int64_t p, cf (&dst)[C::R]) {
+        const bool act = p < p_end;
+        const int64_t s0 = 2 * (act ? p : p_end - 1) * Lb - P1;      // clamped pair: loads stay in range
+        if constexpr (!EDGE) {
+            const float *b0 = x + s0;
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) dst[t] = mk(b0[tid + C::T * t], b0[lb + tid + C::T * t]);
+        } else {
+            const int64_t s1 = s0 + Lb;
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int m = tid + C::T * t;
+                const int64_t i0 = s0 + m, i1 = s1 + m;
+                const bool in0 = i0 >= 0 && i0 < nsamp, in1 = i1 >= 0 && i1 < nsamp;
+                const float a = x[in0 ? i0 : 0], b = x[in1 ? i1 : 0];      // clamped, unconditional
+                dst[t] = mk(in0 ? a : 0.f, in1 ? b : 0.f);
+            }
+        }
+    };
+    cf nxt[C::R];
+    fetch(p_begin + (int64_t)blockIdx.x * C::FPW + grp, nxt);
+    for (int64_t p0 = p_begin + (int64_t)blockIdx.x * C::FPW; p0 < p_end; p0 += stride) {
         const int64_t p = p0 + grp;
-        const bool act = p < npairs;
-        const int64_t s0 = 2 * p * Lb - P1, s1 = s0 + Lb;      // first input sample of each block
+        const bool act = p < p_end;
+        const int64_t s0 = 2 * p * Lb - P1, s1 = s0 + Lb;
         cf v[C::R];
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) {
-            const int m = tid + C::T * t;
-            const int64_t i0 = s0 + m, i1 = s1 + m;
-            const bool in0 = act && i0 >= 0 && i0 < nsamp, in1 = act && i1 >= 0 && i1 < nsamp;
-            const float a = x[in0 ? i0 : 0], b = x[in1 ? i1 : 0];      // clamped, unconditional
-            v[t] = mk(in0 ? a : 0.f, in1 ? b : 0.f);
-        }
+        for (int t = 0; t < C::R; ++t) v[t] = nxt[t];
+        fetch(p + stride, nxt);
+        // the filter spectrum (32 KiB, L2-resident) is re-read every pair instead of pinning 32 VGPRs; the opaque
+        // zero offset stops hipcc from hoisting the loads out of the loop and spilling
+        int hoff = 0;
+        asm volatile("" : "+v"(hoff));
+        cf H[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) H[t] = Hs[hoff + tid + C::T * t];
         xf.fwd(v, lds, tid, N);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = cconj(cmul(v[t], H[t]));
         xf.fwd(v, lds, tid, N);
         if (act) {
+            if constexpr (!EDGE) {
+                float *y0 = y + s0;
 #pragma unroll
-            for (int t = 0; t < C::R; ++t) {
-                const int m = tid + C::T * t;
-                if (m >= P1) {
-                    const int64_t o0 = s0 + m, o1 = s1 + m;
-                    if (o0 < nsamp) y[o0] = v[t].x;
-                    if (o1 < nsamp) y[o1] = -v[t].y;        // conj of the inverse trick
+                for (int t = 0; t < C::R; ++t) {
+                    const int m = tid + C::T * t;
+                    if (m >= P1) {
+                        y0[m] = v[t].x;
+                        y0[lb + m] = -v[t].y;                    // conj of the inverse trick
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < C::R; ++t) {
+                    const int m = tid + C::T * t;
+                    if (m >= P1) {
+                        const int64_t o0 = s0 + m, o1 = s1 + m;
+                        if (o0 < nsamp) y[o0] = v[t].x;
+                        if (o1 < nsamp) y[o1] = -v[t].y;
+                    }
                 }
             }
         }
