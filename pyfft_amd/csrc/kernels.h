@@ -264,6 +264,7 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_rp(const float *__restrict__
         const int64_t base_a = ga * hop, base_b = (has_b ? ga + 1 : ga) * hop;
         const float kb = has_b ? 1.f : 0.f;
         cf v[C::R];
+        // (no software prefetch here: it costs 38 VGPRs = one wave per SIMD and measured no faster)
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int j = tid + C::T * t;
@@ -941,6 +942,15 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
     const int64_t npairs = (nframes + 1) / 2;
     const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
     const int64_t p0 = gid * ppg;
+    // software pipeline: the samples of the next frame pair are loaded while this pair is transformed
+    auto fetch = [&](int64_t p, cf (&dst)[C::R]) {
+        const int64_t ga = 2 * (p < npairs ? p : npairs - 1);
+        const int64_t base_a = ga * hop, base_b = (ga + 1 < nframes ? ga + 1 : ga) * hop;
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) dst[t] = mk(x[base_a + tid + C::T * t], x[base_b + tid + C::T * t]);
+    };
+    cf nxt[C::R];
+    fetch(p0, nxt);
     for (int64_t i = 0; i < ppg; ++i) {
         const int64_t p = p0 + i;
         const bool act = p < npairs;
@@ -950,10 +960,8 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
         cf v[C::R];
         float pwa = 0.f, pwb = 0.f;
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) {
-            const int j = tid + C::T * t;
-            v[t] = mk(x[base_a + j], x[base_b + j]);
-        }
+        for (int t = 0; t < C::R; ++t) v[t] = nxt[t];
+        fetch(p + 1, nxt);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int j = tid + C::T * t;
