@@ -74,12 +74,20 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     dist = None
+    # rehearsal on a one-GPU box: SP_BENCH_ONE_GPU=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
+    # ranks on one device); the driver's real runs use one GPU per rank over RCCL
+    one_gpu = os.environ.get("SP_BENCH_ONE_GPU", "") not in ("", "0")
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     nfft = args.nfft
     hop = nfft // 2
