@@ -98,19 +98,125 @@ template <bool INV> __device__ __forceinline__ void dft16(cf (&x)[16]) {
 #undef SP_SWAP
 }
 
+// ---- radix-16 with FMA-fused ("scaled tangent") twiddles, forward only --------------------------------------------
+// A twiddle w = exp(-i th) is applied as  w = g (1 - i tau),  g = cos th, tau = tan th:  the rotation  x (1 - i tau)
+// costs 2 FMAs, and the real scale g rides along as a PENDING factor that the next radix-4 butterfly absorbs into its
+// additions (a + g c is one FMA).  Normalising a butterfly by its first input's scale leaves three ratios per
+// butterfly; the W16 constants between the two radix-4 stages are folded the same way.  Per twiddled radix-16 pass:
+// 30 (rotate) + 64 + 16 + 64 = 174 VALU instead of 60 + 162; an untwiddled one 144 instead of 162.  cos th = 0 occurs
+// only where the twiddle is exactly -i (or +i): g is clamped to 2^-40 in magnitude there (error 1e-12), tau ~ 1e12
+// stays far from the float range for any data a float FFT could hold; near-zero g elsewhere is >= sin(2 pi/8192).
+struct Tw16 {
+    // f[0..14] tau = tan(th_s), s = 1..15
+    // f[15..18] rb, f[19..22] rc, f[23..26] rd : stage 1, group b: g[b+4]/g[b], g[b+8]/g[b], g[b+12]/g[b+4]  (g[0] = 1)
+    // f[27..30] s1, f[31..34] s2, f[35..38] s3 : stage 2, output c: g[1] K1c, g[2] K2c, g[3] K3c / (g[1] K1c)
+    float f[40];
+    static constexpr int TAU = 0, RB = 15, RC = 19, RD = 23, S1 = 27, S2 = 31, S3 = 35;
+    static constexpr int LDS_PITCH = 44;   // floats per table row: 16-byte aligned, 44 j mod 64 distinct for j < 16 -> b128 reads conflict-free
+};
+
+#define SP_T16 0.41421356237309504880f   // tan(pi/8)
+#define SP_T316 2.41421356237309504880f  // tan(3 pi/8)
+
+// forward radix-4 on (a, gb*b, gc*c, gd*d) with rb = gb, rc = gc, rd = gd/gb; 16 FMAs
+__device__ __forceinline__ void dft4s(cf &a, cf &b, cf &c, cf &d, float rb, float rc, float rd) {
+    const cf t0 = mk(fmaf(rc, c.x, a.x), fmaf(rc, c.y, a.y));
+    const cf t1 = mk(fmaf(-rc, c.x, a.x), fmaf(-rc, c.y, a.y));
+    const cf t2 = mk(fmaf(rd, d.x, b.x), fmaf(rd, d.y, b.y));
+    const cf t3 = mk(fmaf(-rd, d.x, b.x), fmaf(-rd, d.y, b.y));
+    a = mk(fmaf(rb, t2.x, t0.x), fmaf(rb, t2.y, t0.y));
+    c = mk(fmaf(-rb, t2.x, t0.x), fmaf(-rb, t2.y, t0.y));
+    b = mk(fmaf(rb, t3.y, t1.x), fmaf(-rb, t3.x, t1.y));     // t1 + rb (-i t3)
+    d = mk(fmaf(-rb, t3.y, t1.x), fmaf(rb, t3.x, t1.y));
+}
+// x (1 - i t)
+__device__ __forceinline__ cf rot_tan(cf a, float t) { return mk(fmaf(t, a.y, a.x), fmaf(-t, a.x, a.y)); }
+
+template <bool TWD> __device__ __forceinline__ void dft16s(cf (&x)[16], const Tw16 &w) {
+    if constexpr (TWD) {
+#pragma unroll
+        for (int s = 1; s < 16; ++s) x[s] = rot_tan(x[s], w.f[Tw16::TAU + s - 1]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dft4s(x[b], x[b + 4], x[b + 8], x[b + 12], w.f[Tw16::RB + b], w.f[Tw16::RC + b], w.f[Tw16::RD + b]);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dft4<false>(x[b], x[b + 4], x[b + 8], x[b + 12]);
+    }
+    // x[4c+b] = Y[b][c] (pending scale g[b]); rotate by W16^{bc} / K_bc
+    x[5] = rot_tan(x[5], SP_T16);                          // W16^1 = C16 (1 - i tan(pi/8))
+    x[9] = mk(x[9].x + x[9].y, x[9].y - x[9].x);           // W16^2 = C8 (1 - i)
+    x[13] = rot_tan(x[13], SP_T316);                       // W16^3 = S16 (1 - i tan(3pi/8))
+    x[6] = mk(x[6].x + x[6].y, x[6].y - x[6].x);           // W16^2
+    x[10] = mk(x[10].y, -x[10].x);                         // W16^4 = -i
+    x[14] = mk(x[14].x - x[14].y, x[14].y + x[14].x);      // W16^6 = -C8 (1 + i)
+    x[7] = rot_tan(x[7], SP_T316);                         // W16^3
+    x[11] = mk(x[11].x - x[11].y, x[11].y + x[11].x);      // W16^6
+    x[15] = rot_tan(x[15], SP_T16);                        // W16^9 = -C16 (1 - i tan(pi/8))
+    if constexpr (TWD) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dft4s(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3], w.f[Tw16::S1 + c], w.f[Tw16::S2 + c], w.f[Tw16::S3 + c]);
+    } else {
+        dft4<false>(x[0], x[1], x[2], x[3]);
+        dft4s(x[4], x[5], x[6], x[7], SP_C16, SP_C8, SP_S16 / SP_C16);
+        dft4s(x[8], x[9], x[10], x[11], SP_C8, 1.f, -1.f);              // K3c/K1c = -C8/C8
+        dft4s(x[12], x[13], x[14], x[15], SP_S16, -SP_C8, -SP_C16 / SP_S16);
+    }
+    cf t;
+#define SP_SWAP(i, j) t = x[i]; x[i] = x[j]; x[j] = t;
+    SP_SWAP(1, 4) SP_SWAP(2, 8) SP_SWAP(3, 12) SP_SWAP(6, 9) SP_SWAP(7, 13) SP_SWAP(11, 14)
+#undef SP_SWAP
+}
+
+// per-thread constants of a twiddled radix-16 pass from the forward twiddles wv[s-1] = exp(-i s phi), s = 1..15
+__device__ __forceinline__ void make_tw16(Tw16 &w, const cf (&wv)[15]) {
+    float g[16];
+    g[0] = 1.f;
+    w.f[39] = 0.f;
+#pragma unroll
+    for (int s = 1; s < 16; ++s) {
+        float c = wv[s - 1].x;
+        if (fabsf(c) < 9.094947e-13f) c = c < 0.f ? -9.094947e-13f : 9.094947e-13f;   // 2^-40
+        g[s] = c;
+        w.f[Tw16::TAU + s - 1] = -wv[s - 1].y / c;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        w.f[Tw16::RB + b] = g[b + 4] / g[b];
+        w.f[Tw16::RC + b] = g[b + 8] / g[b];
+        w.f[Tw16::RD + b] = g[b + 12] / g[b + 4];
+    }
+    const float K1[4] = {1.f, SP_C16, SP_C8, SP_S16}, K2[4] = {1.f, SP_C8, 1.f, -SP_C8}, K3[4] = {1.f, SP_S16, -SP_C8, -SP_C16};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        w.f[Tw16::S1 + c] = g[1] * K1[c];
+        w.f[Tw16::S2 + c] = g[2] * K2[c];
+        w.f[Tw16::S3 + c] = (g[3] * K3[c]) / (g[1] * K1[c]);
+    }
+}
+
 // SP_ABLATE (diagnostic builds only, results wrong): bit 0 = skip the radix-16 butterflies, bit 1 = skip the LDS
-// exchanges (and their barriers), bit 2 = skip the inter-pass twiddle multiplies
+// exchanges (and their barriers), bit 2 = skip the inter-pass twiddles
+// SP_DIAG_SHARETW (diagnostic, results wrong): every twiddled radix-16 pass uses the first pass's constants
+#ifndef SP_DIAG_SHARETW
+#define SP_DIAG_SHARETW 0
+#endif
 #ifndef SP_ABLATE
 #define SP_ABLATE 0
 #endif
 template <int RDX, bool INV> __device__ __forceinline__ void dftR(cf (&x)[RDX]) {
-    if (RDX == 16 && (SP_ABLATE & 1)) return;
     if constexpr (RDX == 2) dft2<INV>(x[0], x[1]);
     else if constexpr (RDX == 4) dft4<INV>(x[0], x[1], x[2], x[3]);
     else if constexpr (RDX == 8) dft8<INV>(x);
     else if constexpr (RDX == 16) dft16<INV>(x);
 }
 
+// SP_LTW=1 moves the pass-1 twiddle constants to a 16-row LDS table (and, SP_CARRY_WLDS, the carry kernel's window):
+// 163 instead of 213 VGPRs = 3 waves per SIMD for the 4096-point Welch kernel.  Measured equal to the register form
+// (0.645 vs 0.65 ms): the extra LDS reads (+75 % LDS bytes) cost what the third wave gains, because on this CU the
+// kernel's time is close to VALU time + LDS time (tools/ubench/overlap.hip).  Off by default.
+#ifndef SP_LTW
+#define SP_LTW 0
+#endif
 // ---- plan ------------------------------------------------------------------------------
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
 
@@ -133,43 +239,65 @@ template <int N> struct FftPlan {
     // conflict cycles per 4096-point frame.)
     static constexpr int PITCH1 = T + 1;
     static constexpr int LDS_ELEMS = NP > 1 ? (R * PITCH1 > N ? R * PITCH1 : N) : 0;
+    // pass 1 of a 16 x 16 x ... plan has only 16 distinct twiddle sets per workgroup (index tid % 16): they live in a
+    // 16-row LDS table (Tw16::LDS_PITCH floats per row) instead of 39 VGPRs per thread -- the difference between 2 and
+    // 3 waves per SIMD for the 4096-point kernels (measured +10 %)
+    static constexpr bool LTW = SP_LTW && NP16 >= 2;
+    static constexpr int LTW_FLOATS = LTW ? 16 * Tw16::LDS_PITCH : 0;
 };
 
 // ---- the workgroup FFT ------------------------------------------------------------------
-// TWL: the twiddles of pass 1 (radix 16 after one radix-16 pass: W_256^{(q%16) s}, only 16 x 15 distinct values per
-// workgroup) are read from a small LDS table `ltw[(s-1)*16 + q%16]` each frame instead of living in 30 VGPRs.
-template <int N, bool INV, bool TWL = false> struct WgFft {
+// Forward transforms only (inverses are conj(fft(conj(.))) at the call sites).
+template <int N> struct WgFft {
     using PL = FftPlan<N>;
     static constexpr int R = PL::R, T = PL::T, NP = PL::NP;
-    static constexpr bool USE_TWL = TWL && NP >= 2 && PL::radix(1) == 16 && PL::radix(0) == 16;
-    static constexpr int LTW_ELEMS = USE_TWL ? 15 * 16 : 0;
-    cf tw[PL::NTW > 0 ? PL::NTW : 1];
-    const cf *ltw = nullptr;
+    static constexpr int N16 = PL::NP16 > 1 ? PL::NP16 - 1 : 0;          // twiddled radix-16 passes
+    static constexpr int NTR = (N >= 16 && PL::REM > 1) ? (R / PL::REM) * (PL::REM - 1) : 0;   // remainder-pass twiddles
+    static constexpr bool LTW = PL::LTW;
+    static constexpr int N16R = N16 - (LTW ? 1 : 0);                       // ... of which held in registers
+    Tw16 t16[N16R > 0 ? N16R : 1];
+    cf twr[NTR > 0 ? NTR : 1];
+    const float *ltw_row = nullptr;                                         // this thread's row of the LDS table
+
+    // LDS table of the pass-1 constants: rows j = 0..15 <-> tid % 16.  Called by every thread of the workgroup
+    // (wg_tid = threadIdx.x) before the first transform; the caller issues the barrier.
+    __device__ __forceinline__ void fill_lds_twiddles(const cf *__restrict__ table, float *lds_table, int wg_tid, int tid) {
+        if constexpr (LTW) {
+            if (wg_tid < 16) {
+                const int e = wg_tid * (N / 256);
+                cf wv[15];
+#pragma unroll
+                for (int s = 1; s < 16; ++s) wv[s - 1] = table[e * s];
+                Tw16 w;
+                make_tw16(w, wv);
+#pragma unroll
+                for (int i = 0; i < 40; ++i) lds_table[wg_tid * Tw16::LDS_PITCH + i] = w.f[i];
+            }
+            ltw_row = lds_table + (tid & 15) * Tw16::LDS_PITCH;
+        }
+    }
 
     // table[m] = exp(-2 pi i m / N), m = 0..N-1
     __device__ __forceinline__ void load_twiddles(const cf *__restrict__ table, int tid) { load_tw<1>(table, tid); }
 
-    // fill the LDS table (every thread of the workgroup calls this once, then a barrier)
-    __device__ __forceinline__ void fill_lds_twiddles(const cf *__restrict__ table, cf *lds_table, int wg_tid, int wg_size) {
-        if constexpr (USE_TWL) {
-            for (int e = wg_tid; e < 15 * 16; e += wg_size) {
-                const int s = e / 16 + 1, j = e % 16;
-                lds_table[e] = table[(j * s) * (N / 256)];
-            }
-            ltw = lds_table;
-        }
-    }
-
     template <int P> __device__ __forceinline__ void load_tw(const cf *__restrict__ table, int tid) {
         if constexpr (P < NP) {
-            constexpr int r = PL::radix(P), NS = PL::ns(P), NB = R / r, OFF = PL::ntw_before(P);
-            if constexpr (!(USE_TWL && P == 1)) {
+            constexpr int r = PL::radix(P), NS = PL::ns(P), NB = R / r;
+            if constexpr (r == 16) {
+                if constexpr (!(LTW && P == 1)) {
+                    const int e = (tid % NS) * (N / (NS * 16));
+                    cf wv[15];
+#pragma unroll
+                    for (int s = 1; s < 16; ++s) wv[s - 1] = table[e * s];
+                    make_tw16(t16[P - 1 - (LTW ? 1 : 0)], wv);
+                }
+            } else {
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
                     const int q = tid + T * u;
                     const int e = (q % NS) * (N / (NS * r));
 #pragma unroll
-                    for (int s = 1; s < r; ++s) tw[OFF + u * (r - 1) + (s - 1)] = table[e * s];
+                    for (int s = 1; s < r; ++s) twr[u * (r - 1) + (s - 1)] = table[e * s];
                 }
             }
             load_tw<P + 1>(table, tid);
@@ -189,7 +317,7 @@ template <int N, bool INV, bool TWL = false> struct WgFft {
     }
 
     template <int P, bool SINGLE> __device__ __forceinline__ void pass(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
-        constexpr int r = PL::radix(P), NS = PL::ns(P), NB = R / r, OFF = PL::ntw_before(P);
+        constexpr int r = PL::radix(P), NS = PL::ns(P), NB = R / r;
         constexpr bool LAST = (P == NP - 1);
         cf *lds = (P & 1) ? lds1 : lds0;
         if constexpr (!LAST && SINGLE && !(SP_ABLATE & 2)) __syncthreads();   // previous readers of this image are done
@@ -198,17 +326,33 @@ template <int N, bool INV, bool TWL = false> struct WgFft {
             cf x[r];
 #pragma unroll
             for (int s = 0; s < r; ++s) x[s] = v[u + s * NB];
-            if constexpr (P > 0 && !(SP_ABLATE & 4)) {
-                if constexpr (USE_TWL && P == 1) {
-                    const int j = (tid + T * u) & 15;
+            if constexpr (r == 16) {
+                if constexpr (!(SP_ABLATE & 1)) {
+                    if constexpr (P == 1 && LTW && !(SP_ABLATE & 4)) {
+                        Tw16 w;
+                        const float4 *row = reinterpret_cast<const float4 *>(ltw_row);
 #pragma unroll
-                    for (int s = 1; s < r; ++s) x[s] = twm<INV>(x[s], ltw[(s - 1) * 16 + j]);
-                } else {
-#pragma unroll
-                    for (int s = 1; s < r; ++s) x[s] = twm<INV>(x[s], tw[OFF + u * (r - 1) + (s - 1)]);
+                        for (int i = 0; i < 10; ++i) {
+                            const float4 q4 = row[i];
+                            w.f[4 * i] = q4.x;
+                            w.f[4 * i + 1] = q4.y;
+                            w.f[4 * i + 2] = q4.z;
+                            w.f[4 * i + 3] = q4.w;
+                        }
+                        dft16s<true>(x, w);
+                    } else if constexpr (P > 0 && !(SP_ABLATE & 4)) {
+                        dft16s<true>(x, t16[SP_DIAG_SHARETW ? 0 : P - 1 - (LTW ? 1 : 0)]);
+                    } else {
+                        dft16s<false>(x, t16[0]);
+                    }
                 }
+            } else {
+                if constexpr (P > 0 && !(SP_ABLATE & 4)) {
+#pragma unroll
+                    for (int s = 1; s < r; ++s) x[s] = twm<false>(x[s], twr[u * (r - 1) + (s - 1)]);
+                }
+                dftR<r, false>(x);
             }
-            dftR<r, INV>(x);
             if constexpr (LAST || (SP_ABLATE & 2)) {
 #pragma unroll
                 for (int s = 0; s < r; ++s) v[u + s * NB] = x[s];

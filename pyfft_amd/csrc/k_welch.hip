@@ -10,6 +10,16 @@ bool welch_carry_eligible(const Xf &xf, int hop, bool lin) {
     return shift == 4 || shift == 8 || shift == 16;
 }
 
+// SP_CARRY_LDS_PAD=<bytes>: extra dynamic LDS per workgroup, to pin the number of resident workgroups per CU in
+// occupancy experiments
+static size_t carry_lds_pad() {
+    static const size_t v = [] {
+        const char *e = getenv("SP_CARRY_LDS_PAD");
+        return e ? (size_t)atol(e) : (size_t)0;
+    }();
+    return v;
+}
+
 template <int N, bool CPLX>
 static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int64_t nframes, const float *trend,
                       const Xf &xf, float *partial, const RunPart &rp, cf *spartial) {
@@ -18,10 +28,10 @@ static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int
 #define CARRY_(S)                                                                                     \
     case S:                                                                                           \
         if (spartial)                                                                                 \
-            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + (SP_CARRY_TWL ? 240 * sizeof(cf) : 0), c.stream, \
+            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + ((SP_CARRY_WLDS && C::WG == 256 && C::R == 16) ? N * sizeof(float) : 0) + carry_lds_pad(), c.stream, \
                                x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
         else                                                                                          \
-            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + (SP_CARRY_TWL ? 240 * sizeof(cf) : 0), c.stream, \
+            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + ((SP_CARRY_WLDS && C::WG == 256 && C::R == 16) ? N * sizeof(float) : 0) + carry_lds_pad(), c.stream, \
                                x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
         return true;
     switch (shift) {

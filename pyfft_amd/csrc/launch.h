@@ -1,5 +1,6 @@
 // launch.h -- host-side launchers, one translation unit per kernel family so they compile in parallel.
 #pragma once
+#include <stdlib.h>
 #include "kernels.h"
 #include <hip/hip_runtime.h>
 
@@ -27,7 +28,19 @@ struct RunPart {
     int64_t groups, fpg;
     int blocks;
 };
-inline RunPart run_partition(int L, int64_t nframes, int ncu, int groups_per_cu = 8) {
+// groups_per_cu: 8 by default = four rounds at the 2 resident workgroups per CU of the 200-VGPR segment kernels
+// (measured at the metric shape: 8 -> 0.674, 12 -> 0.690 ms).  SP_GROUPS_PER_CU overrides it (experiments; use a
+// multiple of 3 with the 3-wave SP_LTW build).
+inline int default_groups_per_cu() {
+    static const int v = [] {
+        const char *e = getenv("SP_GROUPS_PER_CU");
+        const int k = e ? atoi(e) : 0;
+        return k > 0 ? k : 8;
+    }();
+    return v;
+}
+inline RunPart run_partition(int L, int64_t nframes, int ncu, int groups_per_cu = 0) {
+    if (groups_per_cu <= 0) groups_per_cu = default_groups_per_cu();
     const int fpw = fpw_of(L);
     const int64_t target = (int64_t)ncu * groups_per_cu * fpw;
     int64_t f = (nframes + target - 1) / target;

@@ -849,7 +849,7 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         pyy_d = pxx_d + nb;
         pxy_d = pyy_d + nb * nch;
     }
-    const RunPart rp = run_partition(xf.L, nframes, g.ncu, nch >= 8 ? 2 : 8);
+    const RunPart rp = run_partition(xf.L, nframes, g.ncu, nch >= 8 ? 2 : 0);
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L * 4 * (size_t)nch)) return -1;
     float *partial = (float *)g.work.p;
     if (!cplx && csd_rp_eligible(xf) && !env_flag("SP_NO_REALPAIR")) {
