@@ -160,8 +160,8 @@ def main():
                      "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((args.log2n, nfft)) if world == 1 else None,
                      "kernel": "%s<%d,complex64>" % (E.profile_last_kernel(), nfft),
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "fp32 VALU-issue bound (713 VALU instr per thread-frame); pure streaming floor of this kernel "
-                             "is 0.365 ms = 5.9 TB/s (ablation table, DESIGN.md)"},
+                     "note": "VALU + LDS co-bound: 601 VALU instr and 128 KiB of LDS exchange per 4096-pt frame; alone they "
+                             "take 0.385 / 0.315 ms, pure streaming 0.364 ms = 5.9 TB/s (ablation table, DESIGN.md)"},
     }
 
     if rank == 0 and world == 1 and args.cpu_log2n > 0:

@@ -112,7 +112,6 @@ struct Tw16 {
     // f[27..30] s1, f[31..34] s2, f[35..38] s3 : stage 2, output c: g[1] K1c, g[2] K2c, g[3] K3c / (g[1] K1c)
     float f[40];
     static constexpr int TAU = 0, RB = 15, RC = 19, RD = 23, S1 = 27, S2 = 31, S3 = 35;
-    static constexpr int LDS_PITCH = 44;   // floats per table row: 16-byte aligned, 44 j mod 64 distinct for j < 16 -> b128 reads conflict-free
 };
 
 #define SP_T16 0.41421356237309504880f   // tan(pi/8)
@@ -195,7 +194,7 @@ __device__ __forceinline__ void make_tw16(Tw16 &w, const cf (&wv)[15]) {
 }
 
 // SP_ABLATE (diagnostic builds only, results wrong): bit 0 = skip the radix-16 butterflies, bit 1 = skip the LDS
-// exchanges (and their barriers), bit 2 = skip the inter-pass twiddles
+// exchanges (and their barriers), bit 2 = skip the inter-pass twiddles, bit 3 = no global loads in the carry loop
 // SP_DIAG_SHARETW (diagnostic, results wrong): every twiddled radix-16 pass uses the first pass's constants
 #ifndef SP_DIAG_SHARETW
 #define SP_DIAG_SHARETW 0
@@ -210,13 +209,6 @@ template <int RDX, bool INV> __device__ __forceinline__ void dftR(cf (&x)[RDX]) 
     else if constexpr (RDX == 16) dft16<INV>(x);
 }
 
-// SP_LTW=1 moves the pass-1 twiddle constants to a 16-row LDS table (and, SP_CARRY_WLDS, the carry kernel's window):
-// 163 instead of 213 VGPRs = 3 waves per SIMD for the 4096-point Welch kernel.  Measured equal to the register form
-// (0.645 vs 0.65 ms): the extra LDS reads (+75 % LDS bytes) cost what the third wave gains, because on this CU the
-// kernel's time is close to VALU time + LDS time (tools/ubench/overlap.hip).  Off by default.
-#ifndef SP_LTW
-#define SP_LTW 0
-#endif
 // ---- plan ------------------------------------------------------------------------------
 constexpr int ilog2c(int n) { return n <= 1 ? 0 : 1 + ilog2c(n >> 1); }
 
@@ -239,11 +231,6 @@ template <int N> struct FftPlan {
     // conflict cycles per 4096-point frame.)
     static constexpr int PITCH1 = T + 1;
     static constexpr int LDS_ELEMS = NP > 1 ? (R * PITCH1 > N ? R * PITCH1 : N) : 0;
-    // pass 1 of a 16 x 16 x ... plan has only 16 distinct twiddle sets per workgroup (index tid % 16): they live in a
-    // 16-row LDS table (Tw16::LDS_PITCH floats per row) instead of 39 VGPRs per thread -- the difference between 2 and
-    // 3 waves per SIMD for the 4096-point kernels (measured +10 %)
-    static constexpr bool LTW = SP_LTW && NP16 >= 2;
-    static constexpr int LTW_FLOATS = LTW ? 16 * Tw16::LDS_PITCH : 0;
 };
 
 // ---- the workgroup FFT ------------------------------------------------------------------
@@ -253,29 +240,8 @@ template <int N> struct WgFft {
     static constexpr int R = PL::R, T = PL::T, NP = PL::NP;
     static constexpr int N16 = PL::NP16 > 1 ? PL::NP16 - 1 : 0;          // twiddled radix-16 passes
     static constexpr int NTR = (N >= 16 && PL::REM > 1) ? (R / PL::REM) * (PL::REM - 1) : 0;   // remainder-pass twiddles
-    static constexpr bool LTW = PL::LTW;
-    static constexpr int N16R = N16 - (LTW ? 1 : 0);                       // ... of which held in registers
-    Tw16 t16[N16R > 0 ? N16R : 1];
+    Tw16 t16[N16 > 0 ? N16 : 1];
     cf twr[NTR > 0 ? NTR : 1];
-    const float *ltw_row = nullptr;                                         // this thread's row of the LDS table
-
-    // LDS table of the pass-1 constants: rows j = 0..15 <-> tid % 16.  Called by every thread of the workgroup
-    // (wg_tid = threadIdx.x) before the first transform; the caller issues the barrier.
-    __device__ __forceinline__ void fill_lds_twiddles(const cf *__restrict__ table, float *lds_table, int wg_tid, int tid) {
-        if constexpr (LTW) {
-            if (wg_tid < 16) {
-                const int e = wg_tid * (N / 256);
-                cf wv[15];
-#pragma unroll
-                for (int s = 1; s < 16; ++s) wv[s - 1] = table[e * s];
-                Tw16 w;
-                make_tw16(w, wv);
-#pragma unroll
-                for (int i = 0; i < 40; ++i) lds_table[wg_tid * Tw16::LDS_PITCH + i] = w.f[i];
-            }
-            ltw_row = lds_table + (tid & 15) * Tw16::LDS_PITCH;
-        }
-    }
 
     // table[m] = exp(-2 pi i m / N), m = 0..N-1
     __device__ __forceinline__ void load_twiddles(const cf *__restrict__ table, int tid) { load_tw<1>(table, tid); }
@@ -284,13 +250,11 @@ template <int N> struct WgFft {
         if constexpr (P < NP) {
             constexpr int r = PL::radix(P), NS = PL::ns(P), NB = R / r;
             if constexpr (r == 16) {
-                if constexpr (!(LTW && P == 1)) {
-                    const int e = (tid % NS) * (N / (NS * 16));
-                    cf wv[15];
+                const int e = (tid % NS) * (N / (NS * 16));
+                cf wv[15];
 #pragma unroll
-                    for (int s = 1; s < 16; ++s) wv[s - 1] = table[e * s];
-                    make_tw16(t16[P - 1 - (LTW ? 1 : 0)], wv);
-                }
+                for (int s = 1; s < 16; ++s) wv[s - 1] = table[e * s];
+                make_tw16(t16[P - 1], wv);
             } else {
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
@@ -310,17 +274,10 @@ template <int N> struct WgFft {
         else return i;
     }
 
-    // v[t] <-> element tid + T*t on entry and exit.  lds0/lds1: two exchange images (may be equal,
-    // SINGLE=true, then a barrier also precedes every write).
-    template <bool SINGLE> __device__ __forceinline__ void run(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
-        pass<0, SINGLE>(v, lds0, lds1, tid);
-    }
-
-    template <int P, bool SINGLE> __device__ __forceinline__ void pass(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
-        constexpr int r = PL::radix(P), NS = PL::ns(P), NB = R / r;
-        constexpr bool LAST = (P == NP - 1);
-        cf *lds = (P & 1) ? lds1 : lds0;
-        if constexpr (!LAST && SINGLE && !(SP_ABLATE & 2)) __syncthreads();   // previous readers of this image are done
+    // ---- the three pieces of a pass, usable on their own (software-pipelined callers) -------------------------
+    // butterflies of pass P, in place: v[u + s*NB] is input s and then output s of butterfly u
+    template <int P> __device__ __forceinline__ void bfly(cf (&v)[R], int tid) const {
+        constexpr int r = PL::radix(P), NB = R / r;
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
             cf x[r];
@@ -328,20 +285,8 @@ template <int N> struct WgFft {
             for (int s = 0; s < r; ++s) x[s] = v[u + s * NB];
             if constexpr (r == 16) {
                 if constexpr (!(SP_ABLATE & 1)) {
-                    if constexpr (P == 1 && LTW && !(SP_ABLATE & 4)) {
-                        Tw16 w;
-                        const float4 *row = reinterpret_cast<const float4 *>(ltw_row);
-#pragma unroll
-                        for (int i = 0; i < 10; ++i) {
-                            const float4 q4 = row[i];
-                            w.f[4 * i] = q4.x;
-                            w.f[4 * i + 1] = q4.y;
-                            w.f[4 * i + 2] = q4.z;
-                            w.f[4 * i + 3] = q4.w;
-                        }
-                        dft16s<true>(x, w);
-                    } else if constexpr (P > 0 && !(SP_ABLATE & 4)) {
-                        dft16s<true>(x, t16[SP_DIAG_SHARETW ? 0 : P - 1 - (LTW ? 1 : 0)]);
+                    if constexpr (P > 0 && !(SP_ABLATE & 4)) {
+                        dft16s<true>(x, t16[SP_DIAG_SHARETW ? 0 : P - 1]);
                     } else {
                         dft16s<false>(x, t16[0]);
                     }
@@ -353,29 +298,51 @@ template <int N> struct WgFft {
                 }
                 dftR<r, false>(x);
             }
-            if constexpr (LAST || (SP_ABLATE & 2)) {
 #pragma unroll
-                for (int s = 0; s < r; ++s) v[u + s * NB] = x[s];
-            } else {
-                const int q = tid + T * u;
-                const int base = (q / NS) * (NS * r) + (q % NS);
-#pragma unroll
-                for (int s = 0; s < r; ++s) lds[phys<P>(base + s * NS)] = x[s];
-            }
+            for (int s = 0; s < r; ++s) v[u + s * NB] = x[s];
         }
+    }
+    // Stockham scatter of pass P's outputs into exchange image P
+    template <int P> __device__ __forceinline__ void scatter(const cf (&v)[R], cf *lds, int tid) const {
+        constexpr int r = PL::radix(P), NS = PL::ns(P), NB = R / r;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int q = tid + T * u;
+            const int base = (q / NS) * (NS * r) + (q % NS);
+#pragma unroll
+            for (int s = 0; s < r; ++s) lds[phys<P>(base + s * NS)] = v[u + s * NB];
+        }
+    }
+    // unit-stride gather from exchange image P: v[t] = element tid + T*t
+    template <int P> __device__ __forceinline__ void gather(cf (&v)[R], const cf *lds, int tid) const {
+        if constexpr (P == 0 && (T % 16) == 0 && PL::radix(0) == 16) {
+            // i = tid + T*t  ->  (i%16)*PITCH1 + i/16 = (tid%16)*PITCH1 + tid/16 + (T/16)*t
+            const int b = (tid % 16) * PL::PITCH1 + tid / 16;
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = lds[b + (T / 16) * t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = lds[phys<P>(tid + T * t)];
+        }
+    }
+
+    // v[t] <-> element tid + T*t on entry and exit.  lds0/lds1: two exchange images (may be equal,
+    // SINGLE=true, then a barrier also precedes every write).
+    template <bool SINGLE> __device__ __forceinline__ void run(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
+        pass<0, SINGLE>(v, lds0, lds1, tid);
+    }
+
+    template <int P, bool SINGLE> __device__ __forceinline__ void pass(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
+        constexpr bool LAST = (P == NP - 1);
+        cf *lds = (P & 1) ? lds1 : lds0;
+        if constexpr (!LAST && SINGLE && !(SP_ABLATE & 2)) __syncthreads();   // previous readers of this image are done
+        bfly<P>(v, tid);
         if constexpr (!LAST && (SP_ABLATE & 2)) {
             pass<P + 1, SINGLE>(v, lds0, lds1, tid);
         } else if constexpr (!LAST) {
+            scatter<P>(v, lds, tid);
             __syncthreads();
-            if constexpr (P == 0 && (T % 16) == 0 && PL::radix(0) == 16) {
-                // i = tid + T*t  ->  (i%16)*PITCH1 + i/16 = (tid%16)*PITCH1 + tid/16 + (T/16)*t
-                const int b = (tid % 16) * PL::PITCH1 + tid / 16;
-#pragma unroll
-                for (int t = 0; t < R; ++t) v[t] = lds[b + (T / 16) * t];
-            } else {
-#pragma unroll
-                for (int t = 0; t < R; ++t) v[t] = lds[phys<P>(tid + T * t)];
-            }
+            gather<P>(v, lds, tid);
             pass<P + 1, SINGLE>(v, lds0, lds1, tid);
         }
     }

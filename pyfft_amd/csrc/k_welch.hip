@@ -28,10 +28,10 @@ static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int
 #define CARRY_(S)                                                                                     \
     case S:                                                                                           \
         if (spartial)                                                                                 \
-            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + ((SP_CARRY_WLDS && C::WG == 256 && C::R == 16) ? N * sizeof(float) : 0) + carry_lds_pad(), c.stream, \
+            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + carry_lds_pad(), c.stream, \
                                x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
         else                                                                                          \
-            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + ((SP_CARRY_WLDS && C::WG == 256 && C::R == 16) ? N * sizeof(float) : 0) + carry_lds_pad(), c.stream, \
+            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + carry_lds_pad(), c.stream, \
                                x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
         return true;
     switch (shift) {

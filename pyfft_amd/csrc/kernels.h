@@ -24,8 +24,7 @@ template <int L> struct WgCfg {
     static constexpr int WG = T >= 256 ? T : 256;
     static constexpr int FPW = WG / T;
     static constexpr int LDS_PER = PL::LDS_ELEMS;              // complex elements per transform image
-    static constexpr int LTW_FLOATS = PL::LTW_FLOATS;          // pass-1 twiddle table, at the start of the workgroup's LDS
-    static constexpr size_t lds_bytes(int nbuf) { return (size_t)FPW * LDS_PER * sizeof(cf) * nbuf + LTW_FLOATS * sizeof(float); }
+    static constexpr size_t lds_bytes(int nbuf) { return (size_t)FPW * LDS_PER * sizeof(cf) * nbuf; }
 };
 
 // device tables of one transform length
@@ -41,10 +40,7 @@ template <int N> struct XfPow2 {
     static constexpr bool EXACT = true;      // n == L at compile time
     using C = WgCfg<N>;
     WgFft<N> f;
-    __device__ __forceinline__ void init(const XfTables &tb, int tid, float *lds_table) {
-        f.load_twiddles(tb.tw, tid);
-        f.fill_lds_twiddles(tb.tw, lds_table, (int)threadIdx.x, tid);
-    }
+    __device__ __forceinline__ void init(const XfTables &tb, int tid) { f.load_twiddles(tb.tw, tid); }
     __device__ __forceinline__ void fwd(cf (&v)[C::R], cf *lds, int tid, int) const { f.template run<true>(v, lds, lds, tid); }
     // two exchange images (ping-pong): one barrier per exchange instead of two
     __device__ __forceinline__ void fwd2(cf (&v)[C::R], cf *lds_a, cf *lds_b, int tid) const { f.template run<false>(v, lds_a, lds_b, tid); }
@@ -56,9 +52,8 @@ template <int L_> struct XfBlue {
     using C = WgCfg<L_>;
     WgFft<L_> f;
     const cf *chirp, *bf;
-    __device__ __forceinline__ void init(const XfTables &tb, int tid, float *lds_table) {
+    __device__ __forceinline__ void init(const XfTables &tb, int tid) {
         f.load_twiddles(tb.tw, tid);
-        f.fill_lds_twiddles(tb.tw, lds_table, (int)threadIdx.x, tid);
         chirp = tb.chirp;
         bf = tb.bf;
     }
@@ -124,14 +119,13 @@ template <bool LIN> __device__ __forceinline__ cf detrended(cf a, const Trend &t
 #define SP_KERNEL_PROLOGUE(X)                                                                         \
     using C = typename X::C;                                                                          \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                          \
-    cf *smem = reinterpret_cast<cf *>(smem_raw + C::LTW_FLOATS * sizeof(float));                      \
+    cf *smem = reinterpret_cast<cf *>(smem_raw);                                                      \
     const int grp = C::FPW == 1 ? 0 : (int)threadIdx.x / C::T;                                        \
     const int tid = C::FPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % C::T;                        \
     cf *lds = smem + grp * C::LDS_PER;                                                                \
     const int n = X::EXACT ? X::L : tb.n;                                                             \
     X xf;                                                                                             \
-    xf.init(tb, tid, reinterpret_cast<float *>(smem_raw));                                            \
-    if (C::LTW_FLOATS > 0) __syncthreads();
+    xf.init(tb, tid);
 
 // ------------------------------------------------------------------------------------------
 // A7  batched C2C FFT (fft_analysis.py:2096-2116).  inverse through conj(fft(conj(.)))/n.
@@ -294,18 +288,10 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_rp(const float *__restrict__
 #ifndef SP_CARRY_NBUF
 #define SP_CARRY_NBUF 1
 #endif
-// window of the carry kernel in LDS (1) or registers (0)
-#ifndef SP_CARRY_WLDS
-#define SP_CARRY_WLDS SP_LTW
-#endif
-// SP_CARRY_MINW: force the waves-per-SIMD hint of the carry kernel (diagnostic builds)
-#ifndef SP_CARRY_MINW
-#define SP_CARRY_MINW 0
-#endif
 // (no min-waves hint: capping at 168 VGPRs makes hipcc spill the window registers and reload them inside the
 //  frame loop behind vmcnt(0) waits, which also drains the prefetch loads -- measured 2x slower)
 template <int N, bool CPLX, int SHIFT, bool ONEPASS>
-__global__ __launch_bounds__(WgCfg<N>::WG, SP_CARRY_MINW ? SP_CARRY_MINW : ((WgCfg<N>::WG == 256 && SP_CARRY_WLDS && SHIFT <= 8) ? 3 : 1)) void k_welch_carry(
+__global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
     const void *__restrict__ x, const float *__restrict__ win, int64_t nframes, int64_t fpg,
     const float *__restrict__ trend, XfTables tb, float *__restrict__ partial, cf *__restrict__ spartial) {
     using X = XfPow2<N>;
@@ -315,23 +301,12 @@ __global__ __launch_bounds__(WgCfg<N>::WG, SP_CARRY_MINW ? SP_CARRY_MINW : ((WgC
     constexpr int KEEP = C::R - SHIFT;
     constexpr bool UNI = C::FPW == 1;          // one group per workgroup: trip counts may differ between groups
     const int hop = SHIFT * C::T;
-    // the window lives in LDS (WLDS: as float4 [t/4][tid], conflict-free b128 reads, re-read every frame) so that the
-    // kernel fits 168 VGPRs = 3 waves per SIMD; with it in registers hipcc spills to scratch inside the frame loop
-    constexpr bool WLDS = SP_CARRY_WLDS && C::R == 16 && C::WG == 256;
     float w[C::R], acc[C::R];
     cf sacc[SHIFT];
-    float4 *wl = reinterpret_cast<float4 *>(smem + SP_CARRY_NBUF * C::FPW * C::LDS_PER);
 #pragma unroll
     for (int t = 0; t < C::R; ++t) {
         w[t] = win[tid + C::T * t];
         acc[t] = 0.f;
-    }
-    if constexpr (WLDS) {
-        if (grp == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wl[q * C::T + tid] = make_float4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
-        }
-        __syncthreads();
     }
 #pragma unroll
     for (int s = 0; s < SHIFT; ++s) sacc[s] = mk(0.f, 0.f);
@@ -360,19 +335,8 @@ __global__ __launch_bounds__(WgCfg<N>::WG, SP_CARRY_MINW ? SP_CARRY_MINW : ((WgC
             for (int s = 0; s < SHIFT; ++s) sacc[s] = UNI ? sacc[s] + raw[KEEP + s] : sacc[s] + keep * raw[KEEP + s];
         }
         cf v[C::R];
-        if constexpr (WLDS) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 w4 = wl[q * C::T + tid];
-                v[4 * q] = w4.x * raw[4 * q];
-                v[4 * q + 1] = w4.y * raw[4 * q + 1];
-                v[4 * q + 2] = w4.z * raw[4 * q + 2];
-                v[4 * q + 3] = w4.w * raw[4 * q + 3];
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < C::R; ++t) v[t] = w[t] * raw[t];
-        }
+        for (int t = 0; t < C::R; ++t) v[t] = w[t] * raw[t];
         // prefetch the SHIFT new slots of frame g+1 (clamped at the end of the signal; unused then).  Issued after
         // v is formed so that the incoming samples can take over the registers of the slots that just died.
         cf nx[SHIFT];
@@ -380,7 +344,10 @@ __global__ __launch_bounds__(WgCfg<N>::WG, SP_CARRY_MINW ? SP_CARRY_MINW : ((WgC
             const int64_t gn = g + 1 < nframes ? g + 1 : last;
             const int64_t base = gn * hop + tid + (int64_t)C::T * KEEP;
 #pragma unroll
-            for (int s = 0; s < SHIFT; ++s) nx[s] = load_sample(x, base + C::T * s, CPLX);
+            for (int s = 0; s < SHIFT; ++s) {
+                if constexpr (SP_ABLATE & 8) nx[s] = raw[s] + mu;      // diagnostic: no global loads in the loop
+                else nx[s] = load_sample(x, base + C::T * s, CPLX);
+            }
         }
         if (SP_CARRY_NBUF == 2) {
             // ping-pong exchange images: with an odd number of exchanges per transform the roles swap every frame

@@ -29,8 +29,7 @@ struct RunPart {
     int blocks;
 };
 // groups_per_cu: 8 by default = four rounds at the 2 resident workgroups per CU of the 200-VGPR segment kernels
-// (measured at the metric shape: 8 -> 0.674, 12 -> 0.690 ms).  SP_GROUPS_PER_CU overrides it (experiments; use a
-// multiple of 3 with the 3-wave SP_LTW build).
+// (measured at the metric shape: 8 -> 0.674, 12 -> 0.690 ms).  SP_GROUPS_PER_CU overrides it (experiments).
 inline int default_groups_per_cu() {
     static const int v = [] {
         const char *e = getenv("SP_GROUPS_PER_CU");

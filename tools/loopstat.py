@@ -12,8 +12,11 @@ for nm in re.findall(r'^(_Z\S+):', s, re.M):
     a = s.index('\n' + nm + ':')
     b = s.index('.Lfunc_end', a)
     blocks = re.split(r'\n(\.LBB\d+_\d+):', s[a:b])
-    best = max(range(2, len(blocks), 2), key=lambda i: len(blocks[i]))
-    ins = [l.strip().split()[0] for l in blocks[best].split('\n') if l.strip() and not l.strip().startswith(('.', ';', '//'))]
-    c = Counter(ins)
-    print(d.strip().split('(')[0], 'block', blocks[best - 1], 'instrs', len(ins), 'VALU', sum(v for k, v in c.items() if k.startswith('v_')))
-    print('  ' + ', '.join('%s %d' % kv for kv in c.most_common(30)))
+    print(d.strip().split('(')[0])
+    for i in range(2, len(blocks), 2):
+        ins = [l.strip().split()[0] for l in blocks[i].split('\n') if l.strip() and not l.strip().startswith(('.', ';', '//'))]
+        if len(ins) < 60:
+            continue
+        c = Counter(ins)
+        print(' block', blocks[i - 1], 'instrs', len(ins), 'VALU', sum(v for k, v in c.items() if k.startswith('v_')))
+        print('   ' + ', '.join('%s %d' % kv for kv in c.most_common(24)))
