@@ -112,9 +112,9 @@ int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, doub
 int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *partial, const cf *spartial,
                      int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st, double *sum_out) {
     const int N = xf.L, H = hop, r = N / H;
-    hipLaunchKernelGGL(k_welch_finish, dim3((N + SP_FIN_BINS - 1) / SP_FIN_BINS), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
-                       c.stream, partial, G, N, N, (int)SIDED_RAW, 1.0, st.A, 0);
-    hipLaunchKernelGGL(k_op_reduce_s, dim3((H + 31) / 32), dim3(1024), 0, c.stream, spartial, G, H, st.Sl);
+    hipLaunchKernelGGL(k_op_colsums, dim3((N + 31) / 32 + (2 * H + 31) / 32), dim3(1024), 0, c.stream, partial, N, st.A,
+                       reinterpret_cast<const float *>(spartial), 2 * H, st.Sl, G);
+    if (!sum_out) return 0;          // single-call path: k_op_finish derives the shard mean itself
     if (cplx) hipLaunchKernelGGL((k_op_total<true>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot, st.dlt, sum_out);
     else hipLaunchKernelGGL((k_op_total<false>), dim3(1), dim3(1024), 0, c.stream, x, trend, st.Sl, H, r, nframes, nmean, st.tot, st.dlt, sum_out);
     return 0;
@@ -124,16 +124,15 @@ int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, 
 int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, OnePass st,
                      const double *mean_in, int64_t nmean, const Xf &xf, int hop, int64_t nframes, cf *, const cf *Wf,
                      int sided, double scale, double *out) {
-    (void)nmean;
     const int H = hop, r = xf.L / H;
 #define FIN_(NN)                                                                                      \
     case NN:                                                                                          \
         if (cplx)                                                                                     \
             hipLaunchKernelGGL((k_op_finish<NN, true>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
-                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, sided, scale, xf.tb, out); \
+                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out); \
         else                                                                                          \
             hipLaunchKernelGGL((k_op_finish<NN, false>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
-                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, sided, scale, xf.tb, out); \
+                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out); \
         break;
     switch (xf.L) {
         FIN_(256) FIN_(512) FIN_(1024) FIN_(2048) FIN_(4096) FIN_(8192)

@@ -383,40 +383,39 @@ struct OnePass {
     double *A, *Sl, *tot, *dlt;
 };
 
-// Sl[j] = sum over groups of spartial[g][j]  (complex, H entries); 32 entries x 32 slices per block
-static __global__ __launch_bounds__(1024) void k_op_reduce_s(const cf *__restrict__ sp, int64_t G, int H,
-                                                              double *__restrict__ Sl) {
-    __shared__ double sh[2][32][32];
+// column sums, in double, of two float matrices with G rows in ONE launch: m0[G][c0] -> o0[c0] (the raw |X|^2 sums
+// A[k]) and m1[G][c1] -> o1[c1] (the block sums: spartial[G][H] complex seen as [G][2H] floats -> Sl[2j], Sl[2j+1]).
+// block = 32 columns x 32 row slices (1024 threads), 4 independent loads in flight per thread; deterministic order.
+static __global__ __launch_bounds__(1024) void k_op_colsums(const float *__restrict__ m0, int c0, double *__restrict__ o0,
+                                                             const float *__restrict__ m1, int c1, double *__restrict__ o1,
+                                                             int64_t G) {
+    __shared__ double sh[32][32];
+    const int nb0 = (c0 + 31) / 32;
+    const bool second = (int)blockIdx.x >= nb0;
+    const float *__restrict__ m = second ? m1 : m0;
+    const int cols = second ? c1 : c0;
+    double *__restrict__ o = second ? o1 : o0;
     const int lane = threadIdx.x % 32, sl = threadIdx.x / 32;
-    const int j = blockIdx.x * 32 + lane;
-    double a0 = 0, b0 = 0, a1 = 0, b1 = 0;
-    if (j < H) {
+    const int k = ((int)blockIdx.x - (second ? nb0 : 0)) * 32 + lane;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (k < cols) {
         int64_t g = sl;
         for (; g + 96 < G; g += 128) {
-            const cf v0 = sp[g * H + j], v1 = sp[(g + 32) * H + j], v2 = sp[(g + 64) * H + j], v3 = sp[(g + 96) * H + j];
-            a0 += (double)v0.x + (double)v2.x;
-            b0 += (double)v0.y + (double)v2.y;
-            a1 += (double)v1.x + (double)v3.x;
-            b1 += (double)v1.y + (double)v3.y;
+            const float a0 = m[g * cols + k], a1 = m[(g + 32) * cols + k], a2 = m[(g + 64) * cols + k], a3 = m[(g + 96) * cols + k];
+            s0 += (double)a0;
+            s1 += (double)a1;
+            s2 += (double)a2;
+            s3 += (double)a3;
         }
-        for (; g < G; g += 32) {
-            const cf v = sp[g * H + j];
-            a0 += v.x;
-            b0 += v.y;
-        }
+        for (; g < G; g += 32) s0 += (double)m[g * cols + k];
     }
-    sh[0][sl][lane] = a0 + a1;
-    sh[1][sl][lane] = b0 + b1;
+    sh[sl][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (sl == 0 && j < H) {
-        double ta = 0, tb = 0;
+    if (sl == 0 && k < cols) {
+        double t = 0.0;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) {
-            ta += sh[0][q][lane];
-            tb += sh[1][q][lane];
-        }
-        Sl[2 * j] = ta;
-        Sl[2 * j + 1] = tb;
+        for (int q = 0; q < 32; ++q) t += sh[q][lane];
+        o[k] = t;
     }
 }
 
@@ -485,8 +484,8 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
                                                                     const double *__restrict__ A, const cf *__restrict__ Wf,
                                                                     const double *__restrict__ dlt_local,
                                                                     const double *__restrict__ mean_in, int H, int r,
-                                                                    int64_t M, int sided, double scale, XfTables tb,
-                                                                    double *__restrict__ out) {
+                                                                    int64_t M, int64_t nmean, int sided, double scale,
+                                                                    XfTables tb, double *__restrict__ out) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
@@ -495,9 +494,44 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
     if (mean_in) {
         dr = mean_in[0] - (double)trend[0];
         di = mean_in[1] - (double)trend[1];
-    } else {
+    } else if (dlt_local) {
         dr = dlt_local[0];
         di = dlt_local[1];
+    } else {
+        // the shard's own mean (what k_op_total computes for the split ABI), here without the extra launch:
+        // sum_{i<nmean}(x[i] - mu0) = all block sums + head blocks +/- the ragged end
+        double a = 0, b = 0;
+        for (int j = threadIdx.x; j < H; j += C::WG) {
+            a += Sl[2 * j];
+            b += Sl[2 * j + 1];
+        }
+        const int64_t head = (int64_t)(r - 1) * H, cov = (M + r - 1) * (int64_t)H;
+        for (int64_t i = threadIdx.x; i < head; i += C::WG) {
+            const cf s = load_sample(x, i, CPLX) - mu;
+            a += s.x;
+            b += s.y;
+        }
+        const int64_t lo = nmean > cov ? cov : nmean, hi = nmean > cov ? nmean : cov;
+        const double sgn = nmean > cov ? 1.0 : -1.0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += C::WG) {
+            const cf s = load_sample(x, i, CPLX) - mu;
+            a += sgn * s.x;
+            b += sgn * s.y;
+        }
+        double *red = reinterpret_cast<double *>(smem);           // 2 x WG doubles, before the transform uses the LDS
+        red[threadIdx.x] = a;
+        red[C::WG + threadIdx.x] = b;
+        __syncthreads();
+        for (int o = C::WG / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                red[threadIdx.x] += red[threadIdx.x + o];
+                red[C::WG + threadIdx.x] += red[C::WG + threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        dr = red[0] / (double)nmean;
+        di = red[C::WG] / (double)nmean;
+        __syncthreads();
     }
     cf v[C::R];
 #pragma unroll
@@ -544,14 +578,31 @@ static __global__ __launch_bounds__(1024) void k_op_estimate(const void *__restr
     const int64_t len = nsig / SP_EST_RUNS < SP_EST_LEN ? nsig / SP_EST_RUNS : SP_EST_LEN;     // may be 0 for tiny signals
     const int64_t pitch = nsig / SP_EST_RUNS;
     double a = 0, b = 0;
-    // thread t covers element (t % 64 + 64 j) of runs (t / 64) + 16 m: 64 lanes read 64 consecutive samples
+    // wave w covers runs w, w+16, w+32, w+48; lane l the elements l + 64 j of a run.  All 64 loads of a thread are
+    // independent and unconditional (index clamped, value masked) so that they are in flight together: the kernel
+    // costs one memory round trip instead of sixteen.
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int r = wv; r < SP_EST_RUNS; r += 16)
-        for (int64_t i = lane; i < len; i += 64) {
-            const cf v = load_sample(x, pitch * r + i, CPLX);
-            a += v.x;
-            b += v.y;
+    if (len > 0) {
+#pragma unroll
+        for (int m = 0; m < SP_EST_RUNS / 16; ++m) {
+            const int64_t base = pitch * (wv + 16 * m);
+            cf v[SP_EST_LEN / 64];
+#pragma unroll
+            for (int j = 0; j < SP_EST_LEN / 64; ++j) {
+                const int64_t i = lane + 64 * j;
+                v[j] = load_sample(x, base + (i < len ? i : len - 1), CPLX);
+            }
+            float fa = 0.f, fb = 0.f;          // 16 terms per partial: float is ample, the rest is summed in double
+#pragma unroll
+            for (int j = 0; j < SP_EST_LEN / 64; ++j) {
+                const float keep = (lane + 64 * j) < len ? 1.f : 0.f;
+                fa = fmaf(keep, v[j].x, fa);
+                fb = fmaf(keep, v[j].y, fb);
+            }
+            a += (double)fa;
+            b += (double)fb;
         }
+    }
     sh[0][threadIdx.x] = a;
     sh[1][threadIdx.x] = b;
     __syncthreads();

@@ -208,9 +208,18 @@ struct TableEntry {
 };
 std::map<uint64_t, TableEntry> g_tables;
 
+// content hash of a host table (FNV-1a style, 8 bytes per step: a 4096-point window hashes in ~1 us)
 uint64_t fnv1a(const void *p, size_t n, uint64_t h) {
     const unsigned char *b = (const unsigned char *)p;
-    for (size_t i = 0; i < n; ++i) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        memcpy(&w, b + i, 8);
+        h ^= w;
+        h *= 1099511628211ull;
+        h ^= h >> 29;
+    }
+    for (; i < n; ++i) {
         h ^= b[i];
         h *= 1099511628211ull;
     }
@@ -222,8 +231,11 @@ void tables_release() {
     g_tables.clear();
 }
 
-int get_table(uint64_t kind, const void *host, size_t bytes, void **dev, bool *fresh) {
-    const uint64_t key = fnv1a(host, bytes, 1469598103934665603ull ^ (kind * 0x9E3779B97F4A7C15ull) ^ bytes);
+// device table keyed by the CONTENT of `key_data`.  upload != null: a miss uploads `bytes` from it; upload == null: a
+// miss only allocates `bytes` and reports fresh = true (the caller fills the table, e.g. FFT(window) keyed by the window)
+int get_table_keyed(uint64_t kind, const void *key_data, size_t key_bytes, const void *upload, size_t bytes, void **dev,
+                    bool *fresh) {
+    const uint64_t key = fnv1a(key_data, key_bytes, 1469598103934665603ull ^ (kind * 0x9E3779B97F4A7C15ull) ^ bytes);
     auto it = g_tables.find(key);
     if (it != g_tables.end() && it->second.bytes == bytes) {
         *dev = it->second.dev;
@@ -236,11 +248,14 @@ int get_table(uint64_t kind, const void *host, size_t bytes, void **dev, bool *f
     }
     void *d = nullptr;
     HIPCHK(hipMalloc(&d, bytes));
-    HIPCHK(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+    if (upload) HIPCHK(hipMemcpy(d, upload, bytes, hipMemcpyHostToDevice));
     g_tables[key] = TableEntry{d, bytes};
     *dev = d;
     if (fresh) *fresh = true;
     return 0;
+}
+int get_table(uint64_t kind, const void *host, size_t bytes, void **dev, bool *fresh) {
+    return get_table_keyed(kind, host, bytes, host, bytes, dev, fresh);
 }
 
 __global__ void k_set4(float *dst, float a, float b, float c, float d) {
@@ -461,8 +476,10 @@ int dev_fft_any(const cf *in, cf *out, int64_t n, int64_t batch, int inverse) {
 
 
 // ---- one-pass Welch: accumulate, then finish with a (possibly global) mean ------------------------
+// want_sum: also produce the shard's plain sample sum (split ABI, one more tiny launch); without it the finish kernel
+// derives the shard mean itself
 int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-                       int64_t nmean) {
+                       int64_t nmean, bool want_sum) {
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
     if (!welch_carry_eligible(xf, hop, false))
@@ -471,13 +488,16 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     if (nmean < 1 || nmean > nsig) return fail("sp_welch_accum: nmean must be in [1, nsig]");
     void *win_d;
     if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
-    // Wf = FFT(window), cached with the window
-    std::vector<cf> wc((size_t)nfft);
-    for (int i = 0; i < nfft; ++i) wc[(size_t)i] = make_float2(win[i], 0.f);
+    // Wf = FFT(window), cached under the window's content
     void *Wf_d;
     bool fresh = false;
-    if (get_table(3, wc.data(), sizeof(cf) * (size_t)nfft, &Wf_d, &fresh)) return -1;
-    if (fresh) LAUNCHCHK(launch_fft_c2c(lc(), (const cf *)Wf_d, (cf *)Wf_d, 1, 0, xf));
+    if (get_table_keyed(3, win, sizeof(float) * (size_t)nfft, nullptr, sizeof(cf) * (size_t)nfft, &Wf_d, &fresh)) return -1;
+    if (fresh) {
+        std::vector<cf> wc((size_t)nfft);
+        for (int i = 0; i < nfft; ++i) wc[(size_t)i] = make_float2(win[i], 0.f);
+        HIPCHK(hipMemcpy(Wf_d, wc.data(), sizeof(cf) * (size_t)nfft, hipMemcpyHostToDevice));
+        LAUNCHCHK(launch_fft_c2c(lc(), (const cf *)Wf_d, (cf *)Wf_d, 1, 0, xf));
+    }
     TrendBuf tb;
     if (get_trendbuf(1, &tb)) return -1;
     const RunPart rp = run_partition(xf.L, nframes, g.ncu);
@@ -505,7 +525,9 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
         LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,
                                spartial, &g.last_kernel));
     }
-    LAUNCHCHK(launch_op_reduce(lc(), xd, cplx, tb.f, partial, spartial, rp.groups, xf, hop, nframes, nmean, st, sum_d));
+    if (!want_sum) st.dlt = nullptr;
+    LAUNCHCHK(launch_op_reduce(lc(), xd, cplx, tb.f, partial, spartial, rp.groups, xf, hop, nframes, nmean, st,
+                               want_sum ? sum_d : nullptr));
     g_pend.valid = true;
     g_pend.xd = xd;
     g_pend.cplx = cplx;
@@ -727,7 +749,7 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
     if (cplx && detrend == SP_DETREND_MEAN && allow_carry && !env_flag("SP_WELCH_TWOPASS") &&
         welch_carry_eligible(xf, hop, false)) {
         // global-mean detrend in ONE pass over the signal (estimate + exact correction in the epilogue)
-        if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nsig)) return -1;
+        if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nsig, false)) return -1;
         if (welch_finish_locked(nullptr, nframes, sided, scale, out_d)) return -1;
     } else {
         void *win_d;
@@ -773,7 +795,7 @@ int sp_welch_accum(const void *x, int x_dtype, int64_t nsig, const float *win, i
         HIPCHK(hipMemcpyAsync(g.in0.p, x, esz * (size_t)nsig, hipMemcpyHostToDevice, g.stream));
         xd = g.in0.p;
     }
-    if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean)) return -1;
+    if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, true)) return -1;
     if (sum_out) {
         if (mem) HIPCHK(hipMemcpyAsync(sum_out, g_pend.sum_d, sizeof(double) * 2, hipMemcpyDeviceToDevice, g.stream));
         else {
