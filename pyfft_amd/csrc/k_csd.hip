@@ -82,12 +82,51 @@ int launch_csdm_gemm(LaunchCtx c, const cf *Xt, int nch, int64_t mc, int nb, dou
     return 0;
 }
 
-int launch_csdm_finish(LaunchCtx c, double *G, int nch, int nb, double scale) {
+int launch_csdm_finish(LaunchCtx c, double *G, int nch, int nb, double scale, int blk) {
     const int64_t total = (int64_t)nb * nch * nch;
     int64_t b = (total + 255) / 256;
     if (b > (int64_t)c.ncu * 16) b = (int64_t)c.ncu * 16;
-    hipLaunchKernelGGL(k_csdm_finish, dim3((int)b), dim3(256), 0, c.stream, G, nch, nb, scale);
-    hipLaunchKernelGGL(k_csdm_mirror, dim3((int)b), dim3(256), 0, c.stream, G, nch, nb);
+    hipLaunchKernelGGL(k_csdm_finish, dim3((int)b), dim3(256), 0, c.stream, G, nch, nb, scale, blk);
+    hipLaunchKernelGGL(k_csdm_mirror, dim3((int)b), dim3(256), 0, c.stream, G, nch, nb, blk);
+    return 0;
+}
+
+// MFMA path: Xs[c][g][k] -> Xt2[k][g][c] (zero padded), then one workgroup per (bin, superblock pair, frame slice)
+int launch_csdm_transpose_kgc(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int nchp, int64_t m, int64_t mp, int nb) {
+    dim3 grid((unsigned)((nb + 31) / 32), (unsigned)(nchp / 32), (unsigned)mp);
+    hipLaunchKernelGGL(k_csdm_transpose_kgc, grid, dim3(32, 8), 0, c.stream, Xs, Xt, nch, nchp, m, mp, nb);
+    return 0;
+}
+
+int launch_csdm_mfma(LaunchCtx c, const cf *Xt, int nch, int nchp, int64_t mp, int nb, double *G) {
+    const int nsb = nchp / 64;
+    const int npair = nsb * (nsb - 1) / 2;
+    // Work units = (bin, frame slice), all of equal cost, 2 resident workgroups per CU (204 VGPRs).  Slices (multiples
+    // of 256 frames) only when there are too few bins for >= 4 rounds; then the units that would form a partial last
+    // round (e.g. the 2049th bin of cfg5: 2048 = 4 full rounds) are launched separately, cut 8 times finer, so that no
+    // CU waits for a straggler.  Sliced units add into G atomically.
+    const int64_t slots = (int64_t)c.ncu * 2;
+    const int64_t per_bin = nsb + npair;                                         // workgroups per unit (grid.y)
+    int slices = (int)((slots * 4 + (int64_t)nb * per_bin - 1) / ((int64_t)nb * per_bin));
+    const int max_slices = (int)((mp + 255) / 256);
+    if (slices > max_slices) slices = max_slices;
+    if (slices < 1) slices = 1;
+    int64_t fs = (mp + slices - 1) / slices;
+    fs = (fs + 255) / 256 * 256;
+    slices = (int)((mp + fs - 1) / fs);
+    const int64_t units = (int64_t)nb * slices;
+    int64_t main_units = units * per_bin >= slots ? (units * per_bin / slots) * slots / per_bin : units;
+    if (fs < 8 * 32) main_units = units;                                          // cannot cut finer
+    auto go = [&](int64_t u0, int64_t n, int sl, int64_t f, int atomic) {
+        if (n <= 0) return;
+        hipLaunchKernelGGL((k_csdm_mfma<true>), dim3((unsigned)n, nsb, 1), dim3(256), 0, c.stream, Xt, nch, nchp, mp, nsb, G, f,
+                           u0, sl, atomic);
+        if (nsb > 1)
+            hipLaunchKernelGGL((k_csdm_mfma<false>), dim3((unsigned)n, npair, 1), dim3(256), 0, c.stream, Xt, nch, nchp, mp,
+                               nsb, G, f, u0, sl, atomic);
+    };
+    go(0, main_units, slices, fs, slices > 1);
+    go(main_units * 8, (units - main_units) * 8, slices * 8, fs / 8, 1);
     return 0;
 }
 

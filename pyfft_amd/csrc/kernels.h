@@ -1242,23 +1242,181 @@ static __global__ __launch_bounds__(256) void k_csdm_gemm(const cf *__restrict__
         }
 }
 
+// ---- the same contraction on the matrix cores (default path) -------------------------------------------------
+// G[k] = X_k X_k^H is GEMM-shaped (64 x M times M x 64 per bin), so it runs on MFMA: v_mfma_f32_32x32x2_f32 keeps
+// float32 products and accumulation (the parity tolerance rules out bf16/fp16 operands; a bf16x3 split would be the
+// next step).  Layout: Xt2[k][g][c] -- for one bin and frame the channels are contiguous (padded to a multiple of 64
+// with zeros, frames padded to a multiple of 32 with zero frames), so a wave fetches its MFMA operands straight from
+// HBM with one coalesced global_load_dwordx2 per 32 channels x 2 frames: lane l holds X[c = l%32][frame f + l/32],
+// which is exactly the A (32 x 2) and the B (2 x 32) operand layout of the instruction.  No LDS in the loop.
+//   Re G_ij = sum re_i re_j + im_i im_j        Im G_ij = sum im_i re_j - re_i im_j
+// One workgroup = one bin x one 64-channel superblock pair (blockIdx.y) x one frame slice; its 4 waves (one per SIMD) split the
+// frame pairs of the slice, keep 2 accumulators (Re, Im) per 32 x 32 block, prefetch 4 steps ahead, and are summed
+// through LDS at the end.  DIAG (superblock with itself): blocks (0,0), (0,1), (1,1) only; the rest is mirrored.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define SP_CMM_PF 4
+template <bool DIAG>
+static __global__ __launch_bounds__(256) void k_csdm_mfma(const cf *Xt, int nch, int nchp, int64_t mp, int nsb,
+                                                           double *__restrict__ G /*[nb][nch][nch][2]*/, int64_t fs,
+                                                           int64_t unit0, int slices, int atomic) {
+    __shared__ float red[3][16][64];
+    constexpr int NBLK = DIAG ? 3 : 4;
+    // work unit = (bin, frame slice); blockIdx.x + unit0 enumerates them slice-fastest
+    const int64_t unit = unit0 + blockIdx.x;
+    const int k = (int)(unit / slices), zslice = (int)(unit % slices);
+    int si, sj;
+    if (DIAG) {
+        si = sj = blockIdx.y;
+    } else {
+        // blockIdx.y enumerates the pairs si < sj
+        int rem = blockIdx.y;
+        si = 0;
+        while (rem >= nsb - 1 - si) {
+            rem -= nsb - 1 - si;
+            ++si;
+        }
+        sj = si + 1 + rem;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, col = lane & 31;
+    const int64_t gbeg = (int64_t)zslice * fs, gend = gbeg + fs < mp ? gbeg + fs : mp;          // multiples of 32
+    if (gbeg >= mp) return;                                                                      // empty slice (uniform)
+    const int nsteps = (int)((gend - gbeg) / 8);                                                 // multiple of SP_CMM_PF, >= 4
+    // step s of this wave: frames gbeg + 8 s + 2 wave + {0, 1}
+    const cf *pa = Xt + ((int64_t)k * mp + gbeg + 2 * wave + half) * nchp + si * 64 + col;
+    const cf *pb = Xt + ((int64_t)k * mp + gbeg + 2 * wave + half) * nchp + sj * 64 + col;
+    const int64_t step_stride = (int64_t)8 * nchp;
+    f32x16 accR[NBLK], accI[NBLK];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            accR[b][v] = 0.f;
+            accI[b][v] = 0.f;
+        }
+    // operand ring, SP_CMM_PF steps deep.  The loads are inline asm with hand-placed s_waitcnt: with ordinary loads
+    // hipcc turns the loop-carried operands back into load-then-use inside one iteration (the IR carries the addresses,
+    // not the data), which exposes the whole memory latency at every step.  The body is branch-free: frame padding
+    // makes nsteps a multiple of the depth, loads past the end are clamped to the last step and never used.
+    v2f a0[SP_CMM_PF], a1[SP_CMM_PF], b0[SP_CMM_PF], b1[SP_CMM_PF];
+    const int last = nsteps - 1;
+#define SP_GLOAD2(dst, ptr) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(ptr) : "memory")
+#pragma unroll
+    for (int u = 0; u < SP_CMM_PF; ++u) {
+        const int64_t o = (int64_t)(u < last ? u : last) * step_stride;
+        SP_GLOAD2(a0[u], pa + o);
+        SP_GLOAD2(a1[u], pa + o + 32);
+        if (!DIAG) {
+            SP_GLOAD2(b0[u], pb + o);
+            SP_GLOAD2(b1[u], pb + o + 32);
+        }
+    }
+    for (int s0 = 0; s0 < nsteps; s0 += SP_CMM_PF) {
+#pragma unroll
+        for (int u = 0; u < SP_CMM_PF; ++u) {
+            // the oldest slot's loads are complete when only the (SP_CMM_PF - 1) younger slots' loads are outstanding
+            if (DIAG) asm volatile("s_waitcnt vmcnt(6)" : "+v"(a0[u]), "+v"(a1[u])::"memory");
+            else asm volatile("s_waitcnt vmcnt(12)" : "+v"(a0[u]), "+v"(a1[u]), "+v"(b0[u]), "+v"(b1[u])::"memory");
+            const v2f x0 = a0[u], x1 = a1[u];
+            const v2f y0 = DIAG ? x0 : b0[u], y1 = DIAG ? x1 : b1[u];
+            const float n0 = -x0.x, n1 = -x1.x;
+            // blocks 0: (I=0,J=0)  1: (0,1)  2: (1,1)  3: (1,0); consecutive MFMAs use different accumulators
+            accR[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y0.x, accR[0], 0, 0, 0);
+            accR[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, y1.x, accR[1], 0, 0, 0);
+            accR[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y1.x, accR[2], 0, 0, 0);
+            if constexpr (!DIAG) accR[NBLK - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, y0.x, accR[NBLK - 1], 0, 0, 0);
+            accI[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y0.x, accI[0], 0, 0, 0);
+            accI[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y1.x, accI[1], 0, 0, 0);
+            accI[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y1.x, accI[2], 0, 0, 0);
+            if constexpr (!DIAG) accI[NBLK - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y0.x, accI[NBLK - 1], 0, 0, 0);
+            accR[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y0.y, accR[0], 0, 0, 0);
+            accR[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, y1.y, accR[1], 0, 0, 0);
+            accR[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y1.y, accR[2], 0, 0, 0);
+            if constexpr (!DIAG) accR[NBLK - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, y0.y, accR[NBLK - 1], 0, 0, 0);
+            accI[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(n0, y0.y, accI[0], 0, 0, 0);
+            accI[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(n0, y1.y, accI[1], 0, 0, 0);
+            accI[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(n1, y1.y, accI[2], 0, 0, 0);
+            if constexpr (!DIAG) accI[NBLK - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(n1, y0.y, accI[NBLK - 1], 0, 0, 0);
+            // refill the slot for step s0 + u + SP_CMM_PF
+            const int sn = s0 + u + SP_CMM_PF;
+            const int64_t o = (int64_t)(sn < last ? sn : last) * step_stride;
+            SP_GLOAD2(a0[u], pa + o);
+            SP_GLOAD2(a1[u], pa + o + 32);
+            if (!DIAG) {
+                SP_GLOAD2(b0[u], pb + o);
+                SP_GLOAD2(b1[u], pb + o + 32);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef SP_GLOAD2
+    // sum the four waves through LDS (one 32 x 32 accumulator at a time), then wave 0 adds into the float64 matrix.
+    // Accumulator layout of the instruction: register v of lane l is D[i = 8 (v/4) + 4 (l/32) + v%4][j = l%32].
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const int bi = (b == 0 || b == 1) ? 0 : 1, bj = (b == 0 || b == 3) ? 0 : 1;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            f32x16 &acc = part ? accI[b] : accR[b];
+            __syncthreads();
+            if (wave > 0) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) red[wave - 1][v][lane] = acc[v];
+            }
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float t = (acc[v] + red[0][v][lane]) + (red[1][v][lane] + red[2][v][lane]);
+                    const int i = si * 64 + 32 * bi + 8 * (v / 4) + 4 * half + (v % 4), j = sj * 64 + 32 * bj + col;
+                    if (i < nch && j < nch) {
+                        double *p = G + (((int64_t)k * nch + i) * nch + j) * 2 + part;
+                        if (atomic) atomicAdd(p, (double)t);
+                        else *p += (double)t;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Xs[c][g][k] (k fastest) -> Xt2[k][g][c] (c fastest, nchp channels, mp frames; the padding is written as zeros)
+static __global__ void k_csdm_transpose_kgc(const cf *__restrict__ Xs, cf *__restrict__ Xt, int nch, int nchp, int64_t m,
+                                            int64_t mp, int nb) {
+    __shared__ cf tile[32][33];
+    const int64_t g = blockIdx.z;
+    const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = c0 + j, k = k0 + threadIdx.x;
+        const bool ok = c < nch && g < m && k < nb;
+        const cf v = Xs[ok ? ((int64_t)c * m + g) * nb + k : 0];
+        tile[j][threadIdx.x] = ok ? v : mk(0.f, 0.f);
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int k = k0 + j, c = c0 + threadIdx.x;
+        if (k < nb) Xt[((int64_t)k * mp + g) * nchp + c] = tile[threadIdx.x][j];
+    }
+}
+
 // scale, and fill the blocks below the block diagonal from their Hermitian mirrors
-static __global__ void k_csdm_finish(double *__restrict__ G, int nch, int nb, double scale) {
+// (blk = granularity of the computed upper block triangle: 64 for the VALU kernel, 32 for the MFMA kernel)
+static __global__ void k_csdm_finish(double *__restrict__ G, int nch, int nb, double scale, int blk) {
     const int64_t total = (int64_t)nb * nch * nch;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(e % nch), i = (int)((e / nch) % nch);
-        if (j / SP_CM_B >= i / SP_CM_B) {
+        if (j / blk >= i / blk) {
             G[2 * e] *= scale;
             G[2 * e + 1] *= scale;
         }
     }
 }
-static __global__ void k_csdm_mirror(double *__restrict__ G, int nch, int nb) {
+static __global__ void k_csdm_mirror(double *__restrict__ G, int nch, int nb, int blk) {
     const int64_t total = (int64_t)nb * nch * nch;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(e % nch), i = (int)((e / nch) % nch);
         const int64_t k = e / ((int64_t)nch * nch);
-        if (j / SP_CM_B < i / SP_CM_B) {
+        if (j / blk < i / blk) {
             const int64_t m = ((k * nch + j) * nch + i);
             G[2 * e] = G[2 * m];
             G[2 * e + 1] = -G[2 * m + 1];

@@ -934,13 +934,24 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
     }
     HIPCHK(hipMemsetAsync(G, 0, gbytes, g.stream));
     // frames are processed in chunks so the two spectra buffers stay <= 8 GiB each (and float sums stay short)
-    int64_t mc = ((int64_t)1 << 30) / ((int64_t)nch * nb);
-    if (mc > 8192) mc = 8192;
+    int64_t mc = ((int64_t)1 << 31) / ((int64_t)nch * nb);     // <= 16 GiB per spectra buffer
+    if (mc > 16384) mc = 16384;
     if (mc < 32) mc = 32;
     mc &= ~(int64_t)31;
+    {
+        // equal chunks (a ragged last chunk of a few frames costs whole launches)
+        const int64_t nchunks = (nframes + mc - 1) / mc;
+        mc = (nframes + nchunks - 1) / nchunks;
+        mc = (mc + 31) & ~(int64_t)31;
+    }
     if (mc > nframes) mc = nframes;
+    // contraction on the matrix cores (default) or the VALU kernel (SP_CSDM_VALU=1, kept for A/B tests)
+    const bool use_mfma = !env_flag("SP_CSDM_VALU");
+    const int nchp = (nch + 63) / 64 * 64;                       // MFMA layout: channels padded to whole 64-superblocks,
+    const int64_t mcp = (mc + 31) / 32 * 32;                     // frames to a multiple of 32 (zero filled)
     const size_t sbytes = sizeof(cf) * (size_t)nch * (size_t)mc * (size_t)nb;
-    if (g.cmS.ensure(sbytes) || g.cmT.ensure(sbytes)) return -1;
+    const size_t tbytes = use_mfma ? sizeof(cf) * (size_t)nchp * (size_t)mcp * (size_t)nb : sbytes;
+    if (g.cmS.ensure(sbytes) || g.cmT.ensure(tbytes)) return -1;
     cf *Xs = (cf *)g.cmS.p, *Xt = (cf *)g.cmT.p;
     for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
         const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
@@ -959,10 +970,16 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
                                       (const float *)win_d, hop, m, tb.f + 4 * (nch + c), detrend == 2, xf, rp, SP_SIDED_HALF,
                                       1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
         }
-        LAUNCHCHK(launch_csdm_transpose(lc(), Xs, Xt, nch, m, nb));
-        LAUNCHCHK(launch_csdm_gemm(lc(), Xt, nch, m, nb, G));
+        if (use_mfma) {
+            const int64_t mp = (m + 31) / 32 * 32;
+            LAUNCHCHK(launch_csdm_transpose_kgc(lc(), Xs, Xt, nch, nchp, m, mp, nb));
+            LAUNCHCHK(launch_csdm_mfma(lc(), Xt, nch, nchp, mp, nb, G));
+        } else {
+            LAUNCHCHK(launch_csdm_transpose(lc(), Xs, Xt, nch, m, nb));
+            LAUNCHCHK(launch_csdm_gemm(lc(), Xt, nch, m, nb, G));
+        }
     }
-    LAUNCHCHK(launch_csdm_finish(lc(), G, nch, nb, scale / (double)nframes));
+    LAUNCHCHK(launch_csdm_finish(lc(), G, nch, nb, scale / (double)nframes, use_mfma ? 32 : SP_CM_B));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(g_out, G, gbytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
