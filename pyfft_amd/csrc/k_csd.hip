@@ -130,4 +130,38 @@ int launch_csdm_mfma(LaunchCtx c, const cf *Xt, int nch, int nchp, int64_t mp, i
     return 0;
 }
 
+// fused path (nch <= 64: one channel superblock): bins [0, 16*ngroups) straight from Xs; the remaining 1..16 bins
+// through a gathered copy + k_csdm_mfma
+int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G) {
+    const int nchp = (nch + 63) / 64 * 64;
+    const int ngroups = (nb - 1) / SP_CMF_BINS;
+    if (ngroups > 0) {
+        // frame slices (multiples of 8 frames) when there are fewer bin groups than CUs; sliced units add atomically
+        int slices = (c.ncu + ngroups - 1) / ngroups;
+        if (const char *e = getenv("SP_CSDM_SLICES")) slices = atoi(e);           // experiments
+        const int max_slices = (int)((m + 127) / 128);
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+        int64_t fs = (m + slices - 1) / slices;
+        fs = (fs + SP_CMF_F - 1) / SP_CMF_F * SP_CMF_F;
+        slices = (int)((m + fs - 1) / fs);
+        const size_t lds = 2 * sizeof(cf) * SP_CMF_TILE;                          // 68 KiB
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void *)k_csdm_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(k_csdm_fused, dim3(ngroups * slices), dim3(1024), lds, c.stream, Xs, nch, m, nb, G, fs, slices,
+                           slices > 1);
+    }
+    const int kfirst = SP_CMF_BINS * ngroups, ntail = nb - kfirst;
+    if (ntail > 0) {
+        const int64_t mp = (m + 31) / 32 * 32;
+        hipLaunchKernelGGL(k_csdm_gather_bins, dim3((unsigned)mp), dim3(256), 0, c.stream, Xs, Xt_tail, nch, nchp, m, mp, nb, kfirst,
+                           ntail);
+        if (launch_csdm_mfma(c, Xt_tail, nch, nchp, mp, ntail, G + (int64_t)kfirst * nch * nch * 2)) return -1;
+    }
+    return 0;
+}
+
 }   // namespace sp

@@ -1380,6 +1380,140 @@ static __global__ __launch_bounds__(256) void k_csdm_mfma(const cf *Xt, int nch,
     }
 }
 
+// ---- fused form: no transposed copy of the spectra -------------------------------------------------------------
+// One workgroup of 16 waves owns 16 consecutive bins (wave w <-> bin k0 + w) and reads the STFT output Xs[c][g][k] as
+// it lies: a (channel, frame) row of its 16 bins is one 128-byte line (8-bin groups, 64-byte rows, ran at half the
+// speed: PMC showed 1.4-2.9x the algorithmic HBM bytes and the MFMA pipe 49 % busy).  Tiles of 4 frames x 64 channels
+// x 16 bins (32 KiB) go HBM -> registers -> LDS (double buffered, one barrier per
+// tile); every wave then reads ITS bin's operands from LDS in the MFMA layout (lane l: channel l%32, frame parity l/32;
+// pitch 17 complex per (frame, channel) row keeps the reads conflict-free) and runs the same 12 (16) MFMAs per frame
+// pair as k_csdm_mfma.  Each wave owns its bin's accumulators: no cross-wave reduction.  Work unit = (bin group, frame
+// slice), one 1024-thread workgroup per CU (96 accumulator + 32 other registers per lane).  Only for nch <= 64: a pair
+// of different 64-channel superblocks needs 128 accumulators.  Bins that do not fill a group of 16 (the Nyquist bin of every
+// power-of-two nfft) take the k_csdm_mfma path on a small gathered copy.
+#define SP_CMF_BINS 16
+#define SP_CMF_F 4        // frames per tile
+#define SP_CMF_P 17       // LDS pitch (complex) of one (frame, channel) row
+#define SP_CMF_TILE (SP_CMF_F * 64 * SP_CMF_P)      // complex elements per buffer
+static __global__ __launch_bounds__(1024) void k_csdm_fused(const cf *Xs, int nch, int64_t m, int nb, double *__restrict__ G,
+                                                             int64_t fs, int slices, int atomic) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *lds = reinterpret_cast<cf *>(smem_raw);
+    constexpr int F = SP_CMF_F;
+    const int unit = blockIdx.x;
+    const int k0 = (unit / slices) * SP_CMF_BINS, zslice = unit % slices;
+    const int64_t gbeg = (int64_t)zslice * fs, gend = gbeg + fs < m ? gbeg + fs : m;
+    if (gbeg >= gend) return;
+    const int ntiles = (int)((gend - gbeg + F - 1) / F);
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, half = lane >> 5, col = lane & 31;
+    // staging: 2 passes x (128 rows x 8 parts of 2 bins); row = frame * 64 + channel.  The channel of a thread is
+    // fixed, so is its row base; only 32 arch VGPRs are left beside the 96 accumulators (4 waves per SIMD).
+    const int part = t & 7, rowq = t >> 3, cl = rowq & 63, f0 = rowq >> 6;
+    const float keepc = cl < nch ? 1.f : 0.f;
+    const cf *rowbase = Xs + (int64_t)(cl < nch ? cl : 0) * m * nb + k0 + 2 * part;
+    cf *ldst = lds + (f0 * 64 + cl) * SP_CMF_P + 2 * part;
+    cf st[2][2];
+    float keep[2];
+    auto gfetch = [&](int64_t g0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int64_t g = g0 + f0 + 2 * q;
+            const bool ok = g < gend;
+            const cf *src = rowbase + (ok ? g : gbeg) * nb;          // clamped address; the value is masked at lstore,
+            st[q][0] = src[0];                                       // so nothing here waits for the loads
+            st[q][1] = src[1];
+            keep[q] = ok ? keepc : 0.f;
+        }
+    };
+    auto lstore = [&](int bufsel) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            cf *dst = ldst + bufsel * SP_CMF_TILE + (2 * q * 64) * SP_CMF_P;
+            dst[0] = keep[q] * st[q][0];
+            dst[1] = keep[q] * st[q][1];
+        }
+    };
+    f32x16 accR[3], accI[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            accR[b][v] = 0.f;
+            accI[b][v] = 0.f;
+        }
+    gfetch(gbeg);
+    lstore(0);
+    __syncthreads();
+    const cf *pa0 = lds + (half * 64 + col) * SP_CMF_P + wave;
+    for (int it = 0; it < ntiles; ++it) {
+        const bool more = it + 1 < ntiles;                    // workgroup-uniform
+        if (more) gfetch(gbeg + (int64_t)(it + 1) * F);
+        const cf *pa = pa0 + (it & 1) * SP_CMF_TILE;
+#pragma unroll
+        for (int p = 0; p < F / 2; ++p) {
+            const cf x0 = pa[(2 * p * 64) * SP_CMF_P], x1 = pa[(2 * p * 64 + 32) * SP_CMF_P];
+            const float n0 = -x0.x;
+            // blocks 0: (0,0)  1: (0,1)  2: (1,1); consecutive MFMAs use different accumulators.  On the diagonal blocks
+            // Im G = P - P^T with P = Im Re^T: only P is accumulated (10 MFMAs per frame pair instead of 12), the
+            // transpose is taken once at the end
+            accR[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, x0.x, accR[0], 0, 0, 0);
+            accR[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.x, x1.x, accR[1], 0, 0, 0);
+            accR[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.x, x1.x, accR[2], 0, 0, 0);
+            accI[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, x0.x, accI[0], 0, 0, 0);
+            accI[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, x1.x, accI[1], 0, 0, 0);
+            accI[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, x1.x, accI[2], 0, 0, 0);
+            accR[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, x0.y, accR[0], 0, 0, 0);
+            accR[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0.y, x1.y, accR[1], 0, 0, 0);
+            accR[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1.y, x1.y, accR[2], 0, 0, 0);
+            accI[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(n0, x1.y, accI[1], 0, 0, 0);
+        }
+        if (more) lstore((it + 1) & 1);
+        __syncthreads();
+    }
+    // register v of lane l is D[i = 8 (v/4) + 4 (l/32) + v%4][j = l%32]
+    const int k = k0 + wave;
+    float *tp = reinterpret_cast<float *>(lds) + wave * (32 * 33);       // this wave's 32 x 32 transpose image (pitch 33)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const int bi = b == 2 ? 1 : 0, bj = b == 0 ? 0 : 1;
+        if (b != 1) {
+            // diagonal block: Im = P - P^T
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < 16; ++v) tp[(8 * (v / 4) + 4 * half + (v % 4)) * 33 + col] = accI[b][v];
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < 16; ++v) accI[b][v] -= tp[col * 33 + 8 * (v / 4) + 4 * half + (v % 4)];
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int i = 32 * bi + 8 * (v / 4) + 4 * half + (v % 4), j = 32 * bj + col;
+            if (i < nch && j < nch) {
+                double *p = G + (((int64_t)k * nch + i) * nch + j) * 2;
+                if (atomic) {
+                    atomicAdd(p, (double)accR[b][v]);
+                    atomicAdd(p + 1, (double)accI[b][v]);
+                } else {
+                    p[0] += (double)accR[b][v];
+                    p[1] += (double)accI[b][v];
+                }
+            }
+        }
+    }
+}
+
+// tail bins for the fused path: Xt2[kk][g][c] = Xs[c][g][kfirst + kk], zero padded (kk < ntail <= 16)
+static __global__ void k_csdm_gather_bins(const cf *__restrict__ Xs, cf *__restrict__ Xt, int nch, int nchp, int64_t m, int64_t mp,
+                                          int nb, int kfirst, int ntail) {
+    const int64_t g = blockIdx.x;
+    for (int e = threadIdx.x; e < ntail * nchp; e += blockDim.x) {
+        const int kk = e / nchp, c = e % nchp;
+        const bool ok = c < nch && g < m;
+        const cf v = Xs[ok ? ((int64_t)c * m + g) * nb + kfirst + kk : 0];
+        Xt[((int64_t)kk * mp + g) * nchp + c] = ok ? v : mk(0.f, 0.f);
+    }
+}
+
 // Xs[c][g][k] (k fastest) -> Xt2[k][g][c] (c fastest, nchp channels, mp frames; the padding is written as zeros)
 static __global__ void k_csdm_transpose_kgc(const cf *__restrict__ Xs, cf *__restrict__ Xt, int nch, int nchp, int64_t m,
                                             int64_t mp, int nb) {

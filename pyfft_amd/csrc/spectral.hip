@@ -945,12 +945,15 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
         mc = (mc + 31) & ~(int64_t)31;
     }
     if (mc > nframes) mc = nframes;
-    // contraction on the matrix cores (default) or the VALU kernel (SP_CSDM_VALU=1, kept for A/B tests)
+    // contraction on the matrix cores: fused form reading the STFT output as it lies (default), the form with a
+    // transposed copy (SP_CSDM_TRANSPOSED=1), or the VALU kernel (SP_CSDM_VALU=1); the last two are kept for A/B tests
     const bool use_mfma = !env_flag("SP_CSDM_VALU");
+    const bool use_fused = use_mfma && nch <= 64 && !env_flag("SP_CSDM_TRANSPOSED");   // off-diagonal superblocks need 128 accumulators
     const int nchp = (nch + 63) / 64 * 64;                       // MFMA layout: channels padded to whole 64-superblocks,
     const int64_t mcp = (mc + 31) / 32 * 32;                     // frames to a multiple of 32 (zero filled)
     const size_t sbytes = sizeof(cf) * (size_t)nch * (size_t)mc * (size_t)nb;
-    const size_t tbytes = use_mfma ? sizeof(cf) * (size_t)nchp * (size_t)mcp * (size_t)nb : sbytes;
+    const size_t tbytes = use_fused ? sizeof(cf) * (size_t)nchp * (size_t)mcp * 16
+                                    : (use_mfma ? sizeof(cf) * (size_t)nchp * (size_t)mcp * (size_t)nb : sbytes);
     if (g.cmS.ensure(sbytes) || g.cmT.ensure(tbytes)) return -1;
     cf *Xs = (cf *)g.cmS.p, *Xt = (cf *)g.cmT.p;
     for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
@@ -970,7 +973,9 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
                                       (const float *)win_d, hop, m, tb.f + 4 * (nch + c), detrend == 2, xf, rp, SP_SIDED_HALF,
                                       1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
         }
-        if (use_mfma) {
+        if (use_fused) {
+            LAUNCHCHK(launch_csdm_fused(lc(), Xs, Xt, nch, m, nb, G));
+        } else if (use_mfma) {
             const int64_t mp = (m + 31) / 32 * 32;
             LAUNCHCHK(launch_csdm_transpose_kgc(lc(), Xs, Xt, nch, nchp, m, mp, nb));
             LAUNCHCHK(launch_csdm_mfma(lc(), Xt, nch, nchp, mp, nb, G));
