@@ -543,3 +543,22 @@ def test_mean(E):
     assert abs(E.mean(x) - x.astype(np.float64).mean()) < 1e-9
     z = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000) + (1 - 2j)).astype(np.complex64)
     assert abs(E.mean(z) - z.astype(np.complex128).mean()) < 1e-9
+
+
+@pytest.mark.parametrize("nch,nfft,hop,nsig", [(64, 512, 256, 40000), (37, 256, 64, 9000), (130, 256, 128, 5000)])
+def test_csd_matrix_paths_agree(E, nch, nfft, hop, nsig, monkeypatch):
+    """The three contraction paths -- fused MFMA (default for nch <= 64), MFMA on the transposed copy (default above
+    64 channels), VALU (A/B only) -- give the same matrix"""
+    rng = np.random.default_rng(nch + nfft)
+    x = (rng.standard_normal((nch, nsig)) + 0.3 * rng.standard_normal(nsig)[None, :] + 0.2).astype(np.float32)
+    M = (nsig - nfft) // hop + 1
+    win = O.windows("Hanning", nwins=nfft)
+    g0 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+    monkeypatch.setenv("SP_CSDM_TRANSPOSED", "1")
+    g1 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+    monkeypatch.delenv("SP_CSDM_TRANSPOSED")
+    monkeypatch.setenv("SP_CSDM_VALU", "1")
+    g2 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+    scale = np.abs(g2).max()
+    assert np.max(np.abs(g0 - g2)) <= 2e-6 * scale
+    assert np.max(np.abs(g1 - g2)) <= 2e-6 * scale
