@@ -34,7 +34,7 @@ from pyfft_amd.dist import shard_plan, welch_psd_sharded   # noqa: E402
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB
 # units), profiles/r01_pmc_welch_carry.txt; measured at the default workload only -- null for any other size
-TRAFFIC_BYTES_PER_LAUNCH = {(28, 4096): 1.08218e6 * 1024 * 2 + 65536 * 1024}
+TRAFFIC_BYTES_PER_LAUNCH = {(28, 4096): 1.08248e6 * 1024 * 2 + 65536 * 1024}
 
 
 def synth_stream(n0, n, device, seed):
@@ -60,8 +60,12 @@ def synth_stream(n0, n, device, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-steps", type=int, default=60,
+                    help="untimed steps before the warm-up steps so that the GPU clocks have ramped: the first ~40 "
+                         "steps after idle run 10-25 %% slower (tools/steptrace.py).  A fixed count, not a time, so "
+                         "that every rank issues the same collectives.  0 = off")
     ap.add_argument("--log2n", type=int, default=28, help="samples per GPU = 2^log2n")
     ap.add_argument("--nfft", type=int, default=4096)
     ap.add_argument("--cpu-log2n", type=int, default=28, help="CPU-baseline sample = first 2^k samples (0 = skip)")
@@ -110,7 +114,10 @@ def main():
             return E.welch_psd(x, win, hop, M_local, detrend=True, sided=E.SIDED_TWO, scale=scale)
         return welch_psd_sharded(x, win, plan, scale=scale, sided=E.SIDED_TWO)
 
-    E.profile_enable(True)
+    E.profile_enable(False)          # the HIP-event hook is only switched on for the roofline measurement below
+    for _ in range(max(0, args.settle_steps)):
+        step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         pxx = step()
     torch.cuda.synchronize()
@@ -135,6 +142,7 @@ def main():
     # dominant-kernel duration, HIP events on the launch stream, measured in separate (untimed-region) steps so
     # the event waits do not perturb the timed loop
     kd = []
+    E.profile_enable(True)
     for _ in range(max(5, min(args.steps, 20))):
         step()
         kd.append(E.profile_last_ms())
@@ -153,7 +161,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "Welch PSD, 2^%d complex64 samples per GPU, nfft=%d periodic Hann, hop=%d, "
                                "global mean detrend, two-sided" % (args.log2n, nfft, hop),
-                   "samples_per_gpu": S, "frames_per_gpu": M_local, "parallelism": "segment-sharded x%d, "
+                   "samples_per_gpu": S, "frames_per_gpu": M_local, "settle_steps": args.settle_steps, "parallelism": "segment-sharded x%d, "
                    "one RCCL all-reduce of the %d-bin accumulator" % (world, nfft)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
