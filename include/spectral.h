@@ -105,6 +105,13 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
  *      g_out[nfft/2+1][nch][nch] complex double, = scale/nframes * sum_g X_i conj(X_j), no doubling. */
 int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft,
                   int hop, int64_t nframes, int detrend, double scale, double *g_out, int mem);
+/*      The same with the per-channel constants to remove given by the caller (HOST array means[nch], like
+ *      mean_y of sp_welch_csd): a frame-sharded CSD matrix detrends every shard with the mean of the WHOLE
+ *      record (fft_analysis.py:2148 semantics), obtained from sp_channel_means + an all-reduce. */
+int sp_csd_matrix_means(const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft,
+                        int hop, int64_t nframes, const double *means, double scale, double *g_out, int mem);
+/*      means_out[c] = mean of x[c][0:nsig]  (nch real channels, row stride x_ld); means_out follows `mem`. */
+int sp_channel_means(const float *x, int nch, int64_t nsig, int64_t x_ld, double *means_out, int mem);
 
 /* ---- A8/A9: spectrogram.stft -> fftanal.fft_win (spectrogram.py:140-168, fft_analysis.py:2126-2203)
  *      and spectrogram.specgram (spectrogram.py:91-112).

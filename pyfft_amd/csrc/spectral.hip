@@ -895,12 +895,23 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     return 0;
 }
 
-int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft, int hop,
-                  int64_t nframes, int detrend, double scale, double *g_out, int mem) {
+__global__ void k_set_trends(const double *__restrict__ means, float *__restrict__ trend, int nch) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < nch) {
+        trend[4 * c + 0] = (float)means[c];
+        trend[4 * c + 1] = 0.f;
+        trend[4 * c + 2] = 0.f;
+        trend[4 * c + 3] = 0.f;
+    }
+}
+
+static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft,
+                           int hop, int64_t nframes, int detrend, const double *means_host, double scale, double *g_out,
+                           int mem) {
     if (ensure_init()) return -1;
-    if (check_frames("sp_csd_matrix", nsig, nfft, hop, nframes)) return -1;
-    if (nch < 1 || x_ld < nsig) return fail("sp_csd_matrix: bad nch / x_ld");
-    if (detrend < 0 || detrend > 2) return fail("sp_csd_matrix: detrend must be 0, 1 or 2");
+    if (check_frames(who, nsig, nfft, hop, nframes)) return -1;
+    if (nch < 1 || x_ld < nsig) return fail("%s: bad nch / x_ld", who);
+    if (detrend < 0 || detrend > 2) return fail("%s: detrend must be 0, 1 or 2", who);
     std::lock_guard<std::mutex> lk(g.mu);
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
@@ -916,7 +927,12 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
     if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
     TrendBuf tb;
     if (get_trendbuf(2 * nch, &tb)) return -1;           // second half: trends re-based to the current frame chunk
-    if (detrend == 0) {
+    if (means_host) {
+        // caller-supplied constants (detrend == SP_DETREND_CONST semantics)
+        double *md = tb.d;
+        HIPCHK(hipMemcpyAsync(md, means_host, sizeof(double) * (size_t)nch, hipMemcpyHostToDevice, g.stream));
+        hipLaunchKernelGGL(k_set_trends, dim3((nch + 63) / 64), dim3(64), 0, g.stream, md, tb.f, nch);
+    } else if (detrend == 0) {
         HIPCHK(hipMemsetAsync(tb.f, 0, sizeof(float) * 4 * (size_t)nch, g.stream));
     } else if (nch <= 512) {
         double *scr = moments_scratch();                 // all channels in one launch
@@ -989,6 +1005,40 @@ int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const flo
         HIPCHK(hipMemcpyAsync(g_out, G, gbytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
     }
+    return 0;
+}
+
+int sp_csd_matrix(const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft, int hop,
+                  int64_t nframes, int detrend, double scale, double *g_out, int mem) {
+    return csd_matrix_impl("sp_csd_matrix", x, nch, nsig, x_ld, win, nfft, hop, nframes, detrend, nullptr, scale, g_out, mem);
+}
+
+int sp_csd_matrix_means(const float *x, int nch, int64_t nsig, int64_t x_ld, const float *win, int nfft, int hop,
+                        int64_t nframes, const double *means, double scale, double *g_out, int mem) {
+    if (!means) return fail("sp_csd_matrix_means: means is NULL");
+    return csd_matrix_impl("sp_csd_matrix_means", x, nch, nsig, x_ld, win, nfft, hop, nframes, 0, means, scale, g_out, mem);
+}
+
+int sp_channel_means(const float *x, int nch, int64_t nsig, int64_t x_ld, double *means_out, int mem) {
+    if (ensure_init()) return -1;
+    if (nch < 1 || nch > 512 || nsig < 1 || x_ld < nsig) return fail("sp_channel_means: need 1 <= nch <= 512, 1 <= nsig <= x_ld");
+    std::lock_guard<std::mutex> lk(g.mu);
+    const float *xd = x;
+    if (!mem) {
+        const size_t ib = sizeof(float) * (size_t)x_ld * (size_t)nch;
+        if (g.in0.ensure(ib)) return -1;
+        HIPCHK(hipMemcpyAsync(g.in0.p, x, ib, hipMemcpyHostToDevice, g.stream));
+        xd = (const float *)g.in0.p;
+    }
+    TrendBuf tb;
+    if (get_trendbuf(nch, &tb)) return -1;
+    double *scr = moments_scratch();
+    if (!scr) return -1;
+    LAUNCHCHK(launch_moments(lc(), xd, false, nsig, 1, scr, tb.d, tb.f, nch, x_ld));
+    // tb.d holds 8 doubles per channel, the mean first
+    HIPCHK(hipMemcpy2DAsync(means_out, sizeof(double), tb.d, sizeof(double) * 8, sizeof(double), (size_t)nch,
+                            mem ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, g.stream));
+    if (!mem) HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
 

@@ -1,4 +1,4 @@
-"""Segment-sharded Welch PSD across the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" =
+"""Segment-sharded Welch PSD / CSD matrix and channel-sharded reference-vs-channels CSD across the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" =
 RCCL over xGMI).  The path shards by frames -- every rank owns a contiguous range of segments of one long stream
 plus a (nfft-hop)-sample halo -- and has exactly one real exchange: the averaged-PSD accumulator (nfft doubles,
 32 KiB at nfft=4096: latency-bound on any topology), preceded by a 2-double all-reduce of the sample sums so that the
@@ -67,3 +67,62 @@ def welch_psd_sharded(x_local, win, plan, scale=1.0, sided=2, group=None, backen
     if plan.world > 1:
         dist.all_reduce(pt, group=group)
     return pt if isinstance(p, torch.Tensor) else pt.numpy()
+
+
+def csd_matrix_sharded(x_local, win, plan, scale=1.0, group=None, backend=None):
+    """Full CSD matrix (BASELINE cfg5) of a long multi-channel record from this rank's frame shard x_local[nch,
+    plan.nsamples] (same ShardPlan as the PSD: contiguous frame ranges + halo).  Every channel is detrended with the
+    mean of the WHOLE record: all_reduce(nch doubles) of the shard sample sums first, then each rank contracts its
+    frames and the accumulator -- the only large exchange, (nfft/2+1) x nch x nch complex128, 134 MB at cfg5 -- is
+    summed with one all_reduce.  `backend` = (means, matrix) callables; default: the HIP kernels."""
+    import torch
+    import torch.distributed as dist
+    if backend is None:
+        from . import engine as E
+        means_fn = lambda x, n: E.channel_means(x, n)                                           # noqa: E731
+        matrix_fn = lambda x, w, hop, frames, means, sc: E.csd_matrix(x, w, hop, frames, scale=sc, means=means)   # noqa: E731
+    else:
+        means_fn, matrix_fn = backend
+    m = means_fn(x_local, plan.own_samples)                       # mean over the samples this rank owns
+    is_t = isinstance(m, torch.Tensor)
+    st = (m if is_t else torch.from_numpy(np.asarray(m, dtype=np.float64))) * float(plan.own_samples)
+    if plan.world > 1:
+        dist.all_reduce(st, group=group)
+    gmean = st / float(plan.total_samples)
+    # local contraction normalised by the frames of the whole record, so that the shard results simply add
+    g = matrix_fn(x_local, win, plan.hop, plan.frames, gmean if is_t else gmean.numpy(),
+                  scale * float(plan.frames) / float(plan.frames_total))
+    gt = g if isinstance(g, torch.Tensor) else torch.from_numpy(np.asarray(g, dtype=np.complex128))
+    if plan.world > 1:
+        if gt.is_complex():
+            dist.all_reduce(torch.view_as_real(gt), group=group)
+        else:
+            dist.all_reduce(gt, group=group)
+    return gt if isinstance(g, torch.Tensor) else gt.numpy()
+
+
+def welch_csd_channel_sharded(x, y_local, win, hop, nframes, scale=1.0, sided=2, group=None, backend=None):
+    """Reference signal x against many channels (fft_analysis.py:387-393): the channels are dealt out to the ranks,
+    x is replicated, every signal is whole on its rank -- so there is nothing to reduce; the per-channel spectra are
+    gathered.  Returns (pxx, pyy_all, pxy_all) with the channels of rank 0 first (equal channel counts per rank)."""
+    import torch
+    import torch.distributed as dist
+    if backend is None:
+        from . import engine as E
+        backend = lambda a, b: E.welch_csd(a, b, win, hop, nframes, detrend=True, sided=sided, scale=scale)   # noqa: E731
+    pxx, pyy, pxy = backend(x, y_local)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world == 1:
+        return pxx, pyy, pxy
+    as_t = lambda a: a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))   # noqa: E731
+    outs = []
+    for a in (pyy, pxy):
+        t = as_t(a)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        if t.is_complex():
+            dist.all_gather([torch.view_as_real(p) for p in parts], torch.view_as_real(t), group=group)
+        else:
+            dist.all_gather(parts, t, group=group)
+        cat = torch.cat(parts, dim=0)
+        outs.append(cat if isinstance(a, torch.Tensor) else cat.numpy())
+    return pxx, outs[0], outs[1]

@@ -238,26 +238,62 @@ def welch_csd(x, y, win, hop, nframes, detrend=True, sided=SIDED_ONE, scale=1.0)
     return pxx, pyy, pxy
 
 
-def csd_matrix(x, win, hop, nframes, detrend=True, scale=1.0):
+def csd_matrix(x, win, hop, nframes, detrend=True, scale=1.0, means=None):
     """Full cross-spectral-density matrix of real channels x[nch, nsig]:
-    G[k, i, j] = scale/nframes * sum_g X_i[g,k] conj(X_j[g,k]),  k = 0..nfft/2 (rfft bins, no doubling), complex128."""
+    G[k, i, j] = scale/nframes * sum_g X_i[g,k] conj(X_j[g,k]),  k = 0..nfft/2 (rfft bins, no doubling), complex128.
+    means (nch values): remove these constants instead of each channel's own mean (a frame shard of a longer record
+    passes the means of the WHOLE record, see dist.csd_matrix_sharded)."""
     w = _win32(win)
     nfft = w.size
     nb = nfft // 2 + 1
     want = _detrend_args(detrend, None)[0]
+    mh = None
+    if means is not None:
+        mh = np.ascontiguousarray(means.detach().cpu().numpy() if _is_torch(means) else means, dtype=np.float64).ravel()
     if _is_torch(x):
         _bind_stream(x)
         xs = x.to(torch.float32).contiguous()
         nch, ld = xs.shape
         out = torch.empty((nb, nch, nch), dtype=torch.complex128, device=xs.device)
-        check(lib().sp_csd_matrix(ptr(xs.data_ptr()), nch, ld, ld, ptr(w), nfft, int(hop), int(nframes), want,
-                                  float(scale), ptr(out.data_ptr()), 1))
+        if mh is not None:
+            if mh.size != nch:
+                raise ValueError("means must have one value per channel")
+            check(lib().sp_csd_matrix_means(ptr(xs.data_ptr()), nch, ld, ld, ptr(w), nfft, int(hop), int(nframes), ptr(mh),
+                                            float(scale), ptr(out.data_ptr()), 1))
+        else:
+            check(lib().sp_csd_matrix(ptr(xs.data_ptr()), nch, ld, ld, ptr(w), nfft, int(hop), int(nframes), want,
+                                      float(scale), ptr(out.data_ptr()), 1))
         return out
     xs = np.ascontiguousarray(x, dtype=np.float32)
     nch, ld = xs.shape
     out = np.empty((nb, nch, nch), dtype=np.complex128)
     _ffi.init()
-    check(lib().sp_csd_matrix(ptr(xs), nch, ld, ld, ptr(w), nfft, int(hop), int(nframes), want, float(scale), ptr(out), 0))
+    if mh is not None:
+        if mh.size != nch:
+            raise ValueError("means must have one value per channel")
+        check(lib().sp_csd_matrix_means(ptr(xs), nch, ld, ld, ptr(w), nfft, int(hop), int(nframes), ptr(mh), float(scale),
+                                        ptr(out), 0))
+    else:
+        check(lib().sp_csd_matrix(ptr(xs), nch, ld, ld, ptr(w), nfft, int(hop), int(nframes), want, float(scale), ptr(out), 0))
+    return out
+
+
+def channel_means(x, nsamples=None):
+    """Mean of the first `nsamples` samples of every row of x[nch, nsig] (float32 channels), float64[nch]."""
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = x.to(torch.float32).contiguous()
+        nch, ld = xs.shape
+        n = ld if nsamples is None else int(nsamples)
+        out = torch.empty(nch, dtype=torch.float64, device=xs.device)
+        check(lib().sp_channel_means(ptr(xs.data_ptr()), nch, n, ld, ptr(out.data_ptr()), 1))
+        return out
+    xs = np.ascontiguousarray(x, dtype=np.float32)
+    nch, ld = xs.shape
+    n = ld if nsamples is None else int(nsamples)
+    out = np.empty(nch, dtype=np.float64)
+    _ffi.init()
+    check(lib().sp_channel_means(ptr(xs), nch, n, ld, ptr(out), 0))
     return out
 
 

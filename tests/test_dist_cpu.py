@@ -82,3 +82,87 @@ def test_sharded_welch_matches_single_process(tmp_path, world):
         p = np.load(os.path.join(str(tmp_path), "p%d.npy" % r))
         # (the reference subtracts the mean in the input dtype, complex64 here -- Q6 -- hence 1e-6, not 1e-12)
         np.testing.assert_allclose(p, ref, rtol=1e-6, atol=1e-9 * ref.max())
+
+
+# ---- cfg5: frame-sharded CSD matrix, and the channel-sharded reference-vs-channels CSD -----------------------------
+def _csd_record(nch, total):
+    rng = np.random.default_rng(99)
+    common = rng.standard_normal(total)
+    x = np.stack([(0.2 + 0.1 * c) * np.roll(common, c) + rng.standard_normal(total) + 0.3 * c for c in range(nch)])
+    x[:, : total // 4] += 0.7                                     # shard means differ from the record means
+    return x.astype(np.float32)
+
+
+def _oracle_csd_backend(nfft):
+    def means(x, n):
+        return np.asarray(x, dtype=np.float64)[:, :n].mean(axis=1)
+
+    def matrix(x, win, hop, frames, gmean, scale):
+        xd = np.asarray(x, dtype=np.float64) - np.asarray(gmean)[:, None]
+        return O.csd_matrix(xd, win, nfft, hop, frames, 1.0, detrend_style=0) * np.sum(win ** 2) * scale
+    return means, matrix
+
+
+def _csd_worker(rank, world, port, nch, total, nfft, hop, out_dir):
+    from pyfft_amd.dist import csd_matrix_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = _csd_record(nch, total)
+    win = O.windows("Hanning", nwins=nfft)
+    plan = shard_plan(total, nfft, hop, world, rank)
+    x_local = x[:, plan.first_sample: plan.first_sample + plan.nsamples]
+    g = csd_matrix_sharded(x_local, win, plan, scale=1.0, backend=_oracle_csd_backend(nfft))
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), g)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_csd_matrix_matches_single_process(tmp_path, world):
+    nch, total, nfft, hop = 5, 9000, 256, 128
+    port = 31000 + os.getpid() % 2000 + world
+    mp.spawn(_csd_worker, args=(world, port, nch, total, nfft, hop, str(tmp_path)), nprocs=world, join=True)
+    x = _csd_record(nch, total)
+    win = O.windows("Hanning", nwins=nfft)
+    M = (total - nfft) // hop + 1
+    ref = O.csd_matrix(x.astype(np.float64), win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), "g%d.npy" % r))
+        assert np.max(np.abs(g - ref)) <= 1e-10 * np.abs(ref).max()
+
+
+def _chan_worker(rank, world, port, nch, total, nfft, hop, out_dir):
+    from pyfft_amd.dist import welch_csd_channel_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rec = _csd_record(nch + 1, total).astype(np.float64)
+    x, y = rec[0], rec[1:]
+    per = nch // world
+    y_local = y[rank * per:(rank + 1) * per]
+    win = O.windows("Hanning", nwins=nfft)
+    M = (total - nfft) // hop + 1
+
+    def backend(a, b):          # oracle: one-row CSD from the full-matrix restatement
+        g = O.csd_matrix(np.vstack([a[None, :], b]), win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+        return g[:, 0, 0].real, np.stack([g[:, c, c].real for c in range(1, b.shape[0] + 1)]), \
+            np.stack([g[:, c, 0] for c in range(1, b.shape[0] + 1)])
+    pxx, pyy, pxy = welch_csd_channel_sharded(x, y_local, win, hop, M, backend=backend)
+    np.savez(os.path.join(out_dir, "c%d.npz" % rank), pxx=pxx, pyy=pyy, pxy=pxy)
+    dist.destroy_process_group()
+
+
+def test_channel_sharded_csd_gathers_all_channels(tmp_path):
+    world, nch, total, nfft, hop = 2, 4, 6000, 256, 128
+    port = 33000 + os.getpid() % 2000
+    mp.spawn(_chan_worker, args=(world, port, nch, total, nfft, hop, str(tmp_path)), nprocs=world, join=True)
+    rec = _csd_record(nch + 1, total).astype(np.float64)
+    win = O.windows("Hanning", nwins=nfft)
+    M = (total - nfft) // hop + 1
+    g = O.csd_matrix(rec, win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "c%d.npz" % r))
+        assert d["pyy"].shape == (nch, nfft // 2 + 1) and d["pxy"].shape == (nch, nfft // 2 + 1)
+        for c in range(nch):
+            np.testing.assert_allclose(d["pyy"][c], g[:, c + 1, c + 1].real, rtol=1e-12)
+            np.testing.assert_allclose(d["pxy"][c], g[:, c + 1, 0], rtol=1e-10, atol=1e-12 * np.abs(g).max())

@@ -44,3 +44,61 @@ def test_two_ranks_one_gpu_sharded_welch(tmp_path):
     for r in range(world):
         p = np.load(os.path.join(str(tmp_path), "p%d.npy" % r))
         np.testing.assert_allclose(p, ref, rtol=2e-4, atol=1e-6 * ref.max())
+
+
+def _csd_worker(rank, world, port, nch, total, nfft, hop, out_dir):
+    import torch
+    import torch.distributed as dist
+    from pyfft_amd.dist import shard_plan, csd_matrix_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    x = _csd_record(nch, total)
+    plan = shard_plan(total, nfft, hop, world, rank)
+    x_local = torch.from_numpy(np.ascontiguousarray(x[:, plan.first_sample: plan.first_sample + plan.nsamples])).cuda()
+    win = O.windows("Hanning", nwins=nfft)
+    g = csd_matrix_sharded(x_local, win, plan, scale=1.0)
+    assert g.is_cuda
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), g.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def _csd_record(nch, total):
+    rng = np.random.default_rng(5)
+    common = rng.standard_normal(total)
+    x = np.stack([(0.2 + 0.02 * c) * np.roll(common, c) + rng.standard_normal(total) + 0.05 * c for c in range(nch)])
+    x[:, : total // 3] += 0.9                                     # shard means differ from the record means
+    return x.astype(np.float32)
+
+
+def test_two_ranks_one_gpu_sharded_csd_matrix(tmp_path):
+    """cfg5 shape (reduced): two frame shards of a 64-channel record, HIP kernels on device tensors, the matrix
+    all-reduced; every rank must hold the single-process matrix of the whole record (global-mean detrend)"""
+    import torch.multiprocessing as mp
+    world, nch, total, nfft, hop = 2, 64, 256 + 128 * 300, 256, 128
+    port = 29900 + os.getpid() % 300
+    mp.spawn(_csd_worker, args=(world, port, nch, total, nfft, hop, str(tmp_path)), nprocs=world, join=True)
+    x = _csd_record(nch, total)
+    win = O.windows("Hanning", nwins=nfft)
+    M = (total - nfft) // hop + 1
+    ref = O.csd_matrix(x.astype(np.float64), win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+    for r in range(world):
+        g = np.load(os.path.join(str(tmp_path), "g%d.npy" % r))
+        assert np.max(np.abs(g - ref)) <= 2e-4 * np.abs(ref).max()
+
+
+def test_channel_means_and_given_means(tmp_path):
+    """sp_channel_means / sp_csd_matrix_means: a matrix computed with the caller's constants equals the self-detrended
+    one when the constants are the channel means"""
+    from pyfft_amd import engine as E
+    x = _csd_record(7, 5000)
+    m = E.channel_means(x)
+    np.testing.assert_allclose(m, x.astype(np.float64).mean(axis=1), rtol=1e-6, atol=1e-7)
+    m2 = E.channel_means(x, 1234)
+    np.testing.assert_allclose(m2, x[:, :1234].astype(np.float64).mean(axis=1), rtol=1e-6, atol=1e-7)
+    win = O.windows("Hanning", nwins=256)
+    M = (5000 - 256) // 128 + 1
+    g0 = E.csd_matrix(x, win, 128, M, detrend=True)
+    g1 = E.csd_matrix(x, win, 128, M, means=m)
+    assert np.max(np.abs(g0 - g1)) <= 1e-6 * np.abs(g0).max()
