@@ -53,6 +53,51 @@ int launch_csd_rp(LaunchCtx c, const float *x, const float *y, int nch, int64_t 
     return 0;
 }
 
+// reference-once form: Zx = packed pair spectra of x, then one transform per (channel, frame pair)
+int launch_pairspec(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
+                    const Xf &xf, const RunPart &rp, cf *Zx) {
+#define PS_(NN)                                                                                       \
+    case NN:                                                                                          \
+        if (lin) hipLaunchKernelGGL((k_pairspec<NN, true>), dim3(rp.blocks), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1),    \
+                                    c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, Zx);         \
+        else hipLaunchKernelGGL((k_pairspec<NN, false>), dim3(rp.blocks), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1),       \
+                                c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, Zx);             \
+        break;
+    switch (xf.L) {
+        PS_(32) PS_(64) PS_(128) PS_(256) PS_(512) PS_(1024) PS_(2048) PS_(4096) PS_(8192)
+        default: return -1;
+    }
+#undef PS_
+    return 0;
+}
+
+int launch_csd_pair(LaunchCtx c, const float *y, int nch, int64_t y_ld, const float *win, int hop, int64_t nframes,
+                    const float *trend_y, bool lin, const Xf &xf, const cf *Zx, float *partial, const RunPart &rp) {
+#define CP_(NN)                                                                                       \
+    case NN:                                                                                          \
+        if (lin) hipLaunchKernelGGL((k_welch_csd_pair<NN, true>), dim3(rp.blocks, nch), dim3(WgCfg<NN>::WG),     \
+                                    WgCfg<NN>::lds_bytes(1), c.stream, y, y_ld, win, hop, nframes, rp.fpg, trend_y, xf.tb, Zx, \
+                                    partial, rp.groups);                                              \
+        else hipLaunchKernelGGL((k_welch_csd_pair<NN, false>), dim3(rp.blocks, nch), dim3(WgCfg<NN>::WG),        \
+                                WgCfg<NN>::lds_bytes(1), c.stream, y, y_ld, win, hop, nframes, rp.fpg, trend_y, xf.tb, Zx,     \
+                                partial, rp.groups);                                                  \
+        break;
+    switch (xf.L) {
+        CP_(32) CP_(64) CP_(128) CP_(256) CP_(512) CP_(1024) CP_(2048) CP_(4096) CP_(8192)
+        default: return -1;
+    }
+#undef CP_
+    return 0;
+}
+
+int launch_csd_pair_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
+                           double *pyy, double *pxy) {
+    const int n = xf.tb.n;
+    hipLaunchKernelGGL(k_csd_pair_finish, dim3((n + SP_FIN_BINS - 1) / SP_FIN_BINS, nch), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
+                       c.stream, partial, G, n, nch, sided, scale, pyy, pxy);
+    return 0;
+}
+
 int launch_csd_rp_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
                          double *pxx, double *pyy, double *pxy) {
     const int n = xf.tb.n;

@@ -801,6 +801,177 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd_rp(const float *__re
     }
 }
 
+// ---- reference x against MANY real channels: the reference is transformed once ------------------------------------
+// (fft_analysis.py:387-393 loops the channels against one x)  Every real signal packs two consecutive
+// frames into one transform, Z = F_g + i F_{g+1}.  With A[k] = sum_pairs Zy[k] conj(Zx[k]), the real-input symmetries
+// give   sum_g Y_g conj(X_g) = (A[k] + conj(A[n-k])) / 2   and   sum_g |Y_g|^2 = (a[k] + a[n-k]) / 2,  a = sum |Zy|^2
+// -- the cross-frame terms cancel in the mirror combination, which is taken once, on the accumulated sums, by the finish
+// kernel.  So: k_pairspec writes the reference's packed pair spectra Zx once (npairs x n complex, L2/MALL resident),
+// k_welch_csd_pair does ONE transform per (channel, frame pair) -- half of the x + i y_c form, and without its per-frame
+// mirror exchange -- and reads Zx.  partial per (channel, group): [3][L] = a, Re A, Im A.  Power-of-two n.
+template <int N, bool LIN>
+__global__ __launch_bounds__(WgCfg<N>::WG) void k_pairspec(const float *__restrict__ x, const float *__restrict__ win, int hop,
+                                                            int64_t nframes, int64_t ppg, const float *__restrict__ trend,
+                                                            XfTables tb, cf *__restrict__ out) {
+    using X = XfPow2<N>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
+    float w[C::R];
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) w[t] = win[tid + C::T * t];
+    const Trend tr = load_trend(trend);
+    const int64_t npairs = (nframes + 1) / 2;
+    const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
+    const int64_t p0 = gid * ppg;
+    for (int64_t i = 0; i < ppg; ++i) {
+        const int64_t p = p0 + i;
+        const int64_t ga = 2 * (p < npairs ? p : npairs - 1);
+        const bool has_b = ga + 1 < nframes;
+        const int64_t base_a = ga * hop, base_b = (has_b ? ga + 1 : ga) * hop;
+        const float kb = has_b ? 1.f : 0.f;
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = mk(x[base_a + tid + C::T * t], x[base_b + tid + C::T * t]);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int j = tid + C::T * t;
+            const cf a = detrended<LIN>(mk(v[t].x, 0.f), tr, base_a + j);
+            const cf b = detrended<LIN>(mk(v[t].y, 0.f), tr, base_b + j);
+            v[t] = mk(w[t] * a.x, kb * w[t] * b.x);
+        }
+        xf.fwd(v, lds, tid, N);
+        if (p < npairs) {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) out[p * N + tid + C::T * t] = v[t];
+        }
+    }
+}
+
+template <int N, bool LIN>
+__global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd_pair(const float *__restrict__ y, int64_t y_ld,
+                                                                  const float *__restrict__ win, int hop, int64_t nframes,
+                                                                  int64_t ppg, const float *__restrict__ trend_y, XfTables tb,
+                                                                  const cf *__restrict__ Zx, float *__restrict__ partial,
+                                                                  int64_t groups_total) {
+    using X = XfPow2<N>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
+    const int ch = blockIdx.y;
+    float w[C::R], aa[C::R];
+    cf cc[C::R];
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        w[t] = win[tid + C::T * t];
+        aa[t] = 0.f;
+        cc[t] = mk(0.f, 0.f);
+    }
+    const Trend tr = load_trend(trend_y + 4 * ch);
+    const float *yc = y + (int64_t)ch * y_ld;
+    const int64_t npairs = (nframes + 1) / 2;
+    const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
+    const int64_t p0 = gid * ppg;
+    // pair p -> its two frame bases (clamped past the end; a lone last frame has no second member)
+    auto bases = [&](int64_t p, int64_t &base_a, int64_t &base_b, float &kb) __attribute__((always_inline)) {
+        const int64_t pc = p < npairs ? p : npairs - 1;
+        const int64_t ga = 2 * pc;
+        const bool has_b = ga + 1 < nframes;
+        base_a = ga * hop;
+        base_b = (has_b ? ga + 1 : ga) * hop;
+        kb = has_b ? 1.f : 0.f;
+    };
+    cf raw[C::R];
+    {
+        int64_t ba, bb;
+        float kb;
+        bases(p0, ba, bb, kb);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) raw[t] = mk(yc[ba + tid + C::T * t], yc[bb + tid + C::T * t]);
+    }
+    for (int64_t i = 0; i < ppg; ++i) {
+        const int64_t p = p0 + i;
+        const float keep = p < npairs ? 1.f : 0.f;
+        const int64_t pc = p < npairs ? p : npairs - 1;
+        int64_t base_a, base_b;
+        float kb;
+        bases(p, base_a, base_b, kb);
+        cf v[C::R], zx[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int j = tid + C::T * t;
+            const cf a = detrended<LIN>(mk(raw[t].x, 0.f), tr, base_a + j);
+            const cf b = detrended<LIN>(mk(raw[t].y, 0.f), tr, base_b + j);
+            v[t] = mk(w[t] * a.x, kb * w[t] * b.x);
+        }
+        // in flight during the transform: the samples of the next pair (the reference's spectrum of this pair is read
+        // after it: with both in flight the kernel needs 261 VGPRs = one wave per SIMD)
+        {
+            int64_t na, nb2;
+            float kn;
+            bases(p + 1, na, nb2, kn);
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) raw[t] = mk(yc[na + tid + C::T * t], yc[nb2 + tid + C::T * t]);
+        }
+        xf.fwd(v, lds, tid, N);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) zx[t] = Zx[pc * N + tid + C::T * t];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            aa[t] += keep * cnorm(v[t]);
+            cc[t] = cc[t] + keep * cmulc(v[t], zx[t]);
+        }
+    }
+    float *p = partial + ((int64_t)ch * groups_total + gid) * 3 * N;
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        const int k = tid + C::T * t;
+        p[k] = aa[t];
+        p[N + k] = cc[t].x;
+        p[2 * N + k] = cc[t].y;
+    }
+}
+
+// pyy[ch][slot] = (a[k] + a[n-k]) / 2,  pxy[ch][slot] = (A[k] + conj(A[n-k])) / 2, scaled / doubled per sidedness
+static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_pair_finish(const float *__restrict__ partial,
+                                                                                 int64_t G, int n, int nch, int sided,
+                                                                                 double scale, double *__restrict__ pyy,
+                                                                                 double *__restrict__ pxy) {
+    __shared__ double sh[6][SP_FIN_SLICES][SP_FIN_BINS];
+    const int lane = threadIdx.x % SP_FIN_BINS, sl = threadIdx.x / SP_FIN_BINS;
+    const int k = blockIdx.x * SP_FIN_BINS + lane;
+    const int ch = blockIdx.y;
+    const int nb = nbins_of(n, sided);
+    double s[6] = {0, 0, 0, 0, 0, 0};       // a[k], a[km], Re A[k], Im A[k], Re A[km], Im A[km]
+    const float *p = partial + (int64_t)ch * G * 3 * n;
+    if (k < n) {
+        const int km = k == 0 ? 0 : n - k;
+        for (int64_t g = sl; g < G; g += SP_FIN_SLICES) {
+            s[0] += (double)p[(g * 3 + 0) * n + k];
+            s[1] += (double)p[(g * 3 + 0) * n + km];
+            s[2] += (double)p[(g * 3 + 1) * n + k];
+            s[3] += (double)p[(g * 3 + 2) * n + k];
+            s[4] += (double)p[(g * 3 + 1) * n + km];
+            s[5] += (double)p[(g * 3 + 2) * n + km];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sh[j][sl][lane] = s[j];
+    __syncthreads();
+    if (sl == 0 && k < n) {
+        const int slot = bin_slot(k, n, sided);
+        if (slot >= 0) {
+            double t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+#pragma unroll
+                for (int q = 0; q < SP_FIN_SLICES; ++q) t[j] += sh[j][q][lane];
+            const double m = 0.5 * scale * (bin_doubled(k, n, sided) ? 2.0 : 1.0);
+            pyy[(int64_t)ch * nb + slot] = (t[0] + t[1]) * m;
+            pxy[((int64_t)ch * nb + slot) * 2] = (t[2] + t[4]) * m;
+            pxy[((int64_t)ch * nb + slot) * 2 + 1] = (t[3] - t[5]) * m;
+        }
+    }
+}
+
 static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_rp_finish(const float *__restrict__ partial,
                                                                                int64_t G, int n, int nch, int sided,
                                                                                double scale, double *__restrict__ pxx,

@@ -51,6 +51,22 @@ inline RunPart run_partition(int L, int64_t nframes, int ncu, int groups_per_cu 
     r.groups = (int64_t)r.blocks * fpw;
     return r;
 }
+// the same for kernels whose grid has a second dimension of `ny` independent rows (channels): about 8 workgroups per
+// CU in total, so that the per-group partial spectra (ny x groups x 3..4 x L floats) stay small -- with 63 channels the
+// per-CU rule above wrote and re-read 1.6 GB of partials
+inline RunPart run_partition_2d(int L, int64_t nframes, int ncu, int ny) {
+    const int fpw = fpw_of(L);
+    int64_t target = ((int64_t)ncu * 8 + ny - 1) / (ny > 0 ? ny : 1) * fpw;
+    if (target < 8 * fpw) target = 8 * fpw;
+    int64_t f = (nframes + target - 1) / target;
+    if (f < 1) f = 1;
+    const int64_t G = (nframes + f - 1) / f;
+    RunPart r;
+    r.fpg = f;
+    r.blocks = (int)((G + fpw - 1) / fpw);
+    r.groups = (int64_t)r.blocks * fpw;
+    return r;
+}
 inline int strided_blocks(int L, int64_t items, int ncu) {
     const int fpw = fpw_of(L);
     int64_t b = (items + fpw - 1) / fpw;
@@ -103,6 +119,12 @@ int launch_csd_rp(LaunchCtx c, const float *x, const float *y, int nch, int64_t 
                   const RunPart &rp);
 int launch_csd_rp_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
                          double *pxx, double *pyy, double *pxy);
+int launch_pairspec(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
+                    const Xf &xf, const RunPart &rp, cf *Zx);
+int launch_csd_pair(LaunchCtx c, const float *y, int nch, int64_t y_ld, const float *win, int hop, int64_t nframes,
+                    const float *trend_y, bool lin, const Xf &xf, const cf *Zx, float *partial, const RunPart &rp);
+int launch_csd_pair_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
+                           double *pyy, double *pxy);
 int launch_csdm_transpose(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int64_t mc, int nb);
 int launch_csdm_gemm(LaunchCtx c, const cf *Xt, int nch, int64_t mc, int nb, double *G);
 int launch_csdm_finish(LaunchCtx c, double *G, int nch, int nb, double scale, int blk);

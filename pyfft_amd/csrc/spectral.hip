@@ -859,10 +859,17 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     TrendBuf tb;
     if (get_trendbuf(nch + 1, &tb)) return -1;
     if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_x ? mean_x[0] : 0, mean_x ? mean_x[1] : 0)) return -1;
-    for (int c = 0; c < nch; ++c)
-        if (set_trend(tb, c + 1, (const char *)yd + esz * (size_t)y_ld * (size_t)c, cplx, nsig, detrend,
-                      mean_y ? mean_y[2 * c] : 0, mean_y ? mean_y[2 * c + 1] : 0))
-            return -1;
+    if (detrend != 0 && nch <= 512) {
+        // all channels' means / trend lines in one launch pair (64 channels one by one cost 3 ms of launches)
+        double *scr = moments_scratch();
+        if (!scr) return -1;
+        LAUNCHCHK(launch_moments(lc(), yd, cplx, nsig, detrend, scr, tb.d + 8, tb.f + 4, nch, y_ld));
+    } else {
+        for (int c = 0; c < nch; ++c)
+            if (set_trend(tb, c + 1, (const char *)yd + esz * (size_t)y_ld * (size_t)c, cplx, nsig, detrend,
+                          mean_y ? mean_y[2 * c] : 0, mean_y ? mean_y[2 * c + 1] : 0))
+                return -1;
+    }
     const size_t nb = (size_t)nbins_host(nfft, sided);
     double *pxx_d = pxx, *pyy_d = pyy, *pxy_d = pxy;
     if (!mem) {
@@ -871,10 +878,29 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         pyy_d = pxx_d + nb;
         pxy_d = pyy_d + nb * nch;
     }
-    const RunPart rp = run_partition(xf.L, nframes, g.ncu, nch >= 8 ? 2 : 0);
+    const RunPart rp = run_partition_2d(xf.L, nframes, g.ncu, nch);
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L * 4 * (size_t)nch)) return -1;
     float *partial = (float *)g.work.p;
-    if (!cplx && csd_rp_eligible(xf) && !env_flag("SP_NO_REALPAIR")) {
+    if (!cplx && csd_rp_eligible(xf) && nch >= 2 && nframes >= 2 && !env_flag("SP_NO_REALPAIR") && !env_flag("SP_CSD_XIY")) {
+        // real x against many real channels: the reference's packed pair spectra once, then one transform per
+        // (channel, frame PAIR); Pxx from the real-pair PSD kernel.  (SP_CSD_XIY=1: the x + i y_c form below.)
+        const int64_t npairs = (nframes + 1) / 2;
+        const RunPart rpp = run_partition_2d(xf.L, npairs, g.ncu, nch);
+        if (g.work.ensure(sizeof(float) * (size_t)rpp.groups * xf.L * 4 * (size_t)nch)) return -1;
+        partial = (float *)g.work.p;
+        if (g.cmS.ensure(sizeof(cf) * (size_t)npairs * (size_t)xf.L)) return -1;
+        cf *Zx = (cf *)g.cmS.p;
+        const RunPart rpx = run_partition(xf.L, npairs, g.ncu);
+        LAUNCHCHK(launch_pairspec(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rpx, Zx));
+        LAUNCHCHK(launch_csd_pair(lc(), (const float *)yd, nch, y_ld, (const float *)win_d, hop, nframes, tb.f + 4, detrend == 2,
+                                  xf, Zx, partial, rpp));
+        LAUNCHCHK(launch_csd_pair_finish(lc(), partial, rpp.groups, xf, nch, sided, scale / (double)nframes, pyy_d, pxy_d));
+        // Pxx: real-pair Welch PSD of x (its own small partial buffer after the channels' one)
+        if (g.bigT.ensure(sizeof(float) * (size_t)rpx.groups * xf.L)) return -1;
+        float *px = (float *)g.bigT.p;
+        LAUNCHCHK(launch_welch_rp(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, px, rpx));
+        LAUNCHCHK(launch_welch_finish(lc(), px, rpx.groups, xf, sided, scale / (double)nframes, pxx_d, 1));
+    } else if (!cplx && csd_rp_eligible(xf) && !env_flag("SP_NO_REALPAIR")) {
         // real x, y: x + i y_c in one transform per (frame, channel)
         LAUNCHCHK(launch_csd_rp(lc(), (const float *)xd, (const float *)yd, nch, y_ld, (const float *)win_d, hop, nframes,
                                 tb.f, tb.f + 4, detrend == 2, xf, partial, rp));

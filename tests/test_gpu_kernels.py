@@ -562,3 +562,24 @@ def test_csd_matrix_paths_agree(E, nch, nfft, hop, nsig, monkeypatch):
     scale = np.abs(g2).max()
     assert np.max(np.abs(g0 - g2)) <= 2e-6 * scale
     assert np.max(np.abs(g1 - g2)) <= 2e-6 * scale
+
+
+@pytest.mark.parametrize("nfft,hop,n,nch,detrend", [(1024, 512, 1024 + 512 * 40, 5, True), (256, 64, 256 + 64 * 37, 2, "linear"),
+                                                    (4096, 2048, 4096 + 2048 * 9, 3, True)])
+def test_welch_csd_reference_once_path(E, nfft, hop, n, nch, detrend, monkeypatch):
+    """reference-once pair form (default for >= 2 real channels) == x + i y_c form == plain complex form; odd and even
+    frame counts, mean and linear detrend"""
+    rng = np.random.default_rng(nfft + nch)
+    k = np.arange(n)
+    x = (np.sin(0.11 * k) + 0.3 * rng.standard_normal(n) - 0.4 + 1e-4 * k).astype(np.float32)
+    y = np.stack([0.5 * np.sin(0.11 * k + 0.3 * c) + 0.2 * rng.standard_normal(n) + 0.1 * c for c in range(nch)]).astype(np.float32)
+    M = (n - nfft) // hop + 1
+    win = O.windows("Hanning", nwins=nfft)
+    a = E.welch_csd(x, y, win, hop, M, detrend=detrend, sided=E.SIDED_TWO, scale=1.0)
+    monkeypatch.setenv("SP_CSD_XIY", "1")
+    b = E.welch_csd(x, y, win, hop, M, detrend=detrend, sided=E.SIDED_TWO, scale=1.0)
+    monkeypatch.setenv("SP_NO_REALPAIR", "1")
+    c = E.welch_csd(x, y, win, hop, M, detrend=detrend, sided=E.SIDED_TWO, scale=1.0)
+    for u, v, w in zip(a, b, c):
+        assert np.max(np.abs(u - w)) <= 3e-5 * np.abs(w).max()
+        assert np.max(np.abs(v - w)) <= 3e-5 * np.abs(w).max()
