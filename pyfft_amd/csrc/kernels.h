@@ -310,7 +310,10 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
     }
 #pragma unroll
     for (int s = 0; s < SHIFT; ++s) sacc[s] = mk(0.f, 0.f);
-    const cf mu = load_trend(trend).m;
+    cf mu = load_trend(trend).m;
+    // keep the constant in VGPRs: a VALU instruction with an SGPR source issues at half rate on gfx950
+    // (tools/ubench/vgpr_bank.hip), and it is subtracted from every arriving sample
+    asm volatile("" : "+v"(mu.x), "+v"(mu.y));
     const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
     const int64_t g0 = gid * fpg;
     const int64_t last = nframes - 1;
@@ -342,11 +345,23 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
         cf nx[SHIFT];
         {
             const int64_t gn = g + 1 < nframes ? g + 1 : last;
-            const int64_t base = gn * hop + tid + (int64_t)C::T * KEEP;
+            if constexpr (UNI && !(SP_ABLATE & 8)) {
+                // one group per workgroup: the frame base is uniform -> scalar base pointer + 32-bit lane offset, no
+                // 64-bit VALU address arithmetic in the loop
+                const int64_t ubase = gn * hop + (int64_t)C::T * KEEP;
 #pragma unroll
-            for (int s = 0; s < SHIFT; ++s) {
-                if constexpr (SP_ABLATE & 8) nx[s] = raw[s] + mu;      // diagnostic: no global loads in the loop
-                else nx[s] = load_sample(x, base + C::T * s, CPLX);
+                for (int s = 0; s < SHIFT; ++s) {
+                    const unsigned off = (unsigned)(tid + C::T * s);
+                    if (CPLX) nx[s] = (reinterpret_cast<const cf *>(x) + ubase)[off];
+                    else nx[s] = mk((reinterpret_cast<const float *>(x) + ubase)[off], 0.f);
+                }
+            } else {
+                const int64_t base = gn * hop + tid + (int64_t)C::T * KEEP;
+#pragma unroll
+                for (int s = 0; s < SHIFT; ++s) {
+                    if constexpr (SP_ABLATE & 8) nx[s] = raw[s] + mu;      // diagnostic: no global loads in the loop
+                    else nx[s] = load_sample(x, base + C::T * s, CPLX);
+                }
             }
         }
         if (SP_CARRY_NBUF == 2) {
