@@ -10,7 +10,7 @@ SRCS    := $(wildcard $(CSRC)/*.hip)
 OBJS    := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HDRS    := $(wildcard $(CSRC)/*.h) include/spectral.h
 
-all: $(LIBDIR)/libspectral.so
+all: $(LIBDIR)/libspectral.so $(LIBDIR)/libspectral_packed.so
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(HDRS) Makefile
 	@mkdir -p $(OBJDIR)
@@ -20,7 +20,18 @@ $(LIBDIR)/libspectral.so: $(OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
 
+# the same library with the radix-16 butterflies in packed fp32 (fft_core.h, SP_PACKED): an option that measured no
+# faster; built so that tests/test_gpu_variants.py keeps it correct
+POBJDIR := build/obj_packed
+POBJS   := $(patsubst $(CSRC)/%.hip,$(POBJDIR)/%.o,$(SRCS))
+$(POBJDIR)/%.o: $(CSRC)/%.hip $(HDRS) Makefile
+	@mkdir -p $(POBJDIR)
+	$(HIPCC) $(FLAGS) -DSP_PACKED=1 -c $< -o $@
+$(LIBDIR)/libspectral_packed.so: $(POBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(POBJS) -o $@
+
 clean:
-	rm -rf build $(LIBDIR)/libspectral.so
+	rm -rf build $(LIBDIR)/libspectral.so $(LIBDIR)/libspectral_packed.so
 
 .PHONY: all clean

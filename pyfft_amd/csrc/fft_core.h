@@ -166,6 +166,141 @@ template <bool TWD> __device__ __forceinline__ void dft16s(cf (&x)[16], const Tw
 #undef SP_SWAP
 }
 
+// ---- the same butterflies in packed fp32 (v_pk_fma_f32 / v_pk_add_f32), SP_PACKED=1 ---------------------------------
+// A complex value is one 64-bit register pair and every butterfly line is ONE packed instruction; the swap of re/im,
+// the broadcast of a real scale out of a register pair and the signs ride in the op_sel / neg modifiers (inline asm:
+// hipcc folds whole-vector negations and swizzles but materialises mixed-sign operands).  87 (twiddled) / 72 (first
+// pass) instructions per radix-16 instead of 174 / 144; the SIMD's packed rate is the same flops per cycle as the
+// scalar one, but one wave alone can reach it (a wave issues at most one VALU instruction per ~5.5 cycles whatever the
+// instruction does, tools/ubench/valu_rate.hip).  Bit-identical results, all tests pass -- and MEASURED NO FASTER:
+// Welch 0.665 vs 0.640 ms, FFT / STFT / FIR equal within 1-7 % (profiles/r01_ubench.txt notes).  Kept as an option;
+// the scalar form is the default.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f to_v2f(cf a) { return (v2f){a.x, a.y}; }
+__device__ __forceinline__ cf to_cf(v2f a) { return mk(a.x, a.y); }
+// a + (NEG ? -1 : 1) * s[H] * c          (s[H]: half H of the pair s, broadcast)
+template <int H, int NEG> __device__ __forceinline__ v2f pk_sfma(v2f s, v2f c, v2f a) {
+    v2f d;
+    if constexpr (H == 0 && NEG == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(d) : "v"(s), "v"(c), "v"(a));
+    if constexpr (H == 1 && NEG == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(s), "v"(c), "v"(a));
+    if constexpr (H == 0 && NEG == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(s), "v"(c), "v"(a));
+    if constexpr (H == 1 && NEG == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(s), "v"(c), "v"(a));
+    return d;
+}
+// a + (NEG ? -1 : 1) * s[H] * (-i c)  =  (a.x +- s c.y,  a.y -+ s c.x)
+template <int H, int NEG> __device__ __forceinline__ v2f pk_srot(v2f s, v2f c, v2f a) {
+    v2f d;
+    if constexpr (H == 0 && NEG == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(s), "v"(c), "v"(a));
+    if constexpr (H == 1 && NEG == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[1,0,0]" : "=v"(d) : "v"(s), "v"(c), "v"(a));
+    if constexpr (H == 0 && NEG == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(s), "v"(c), "v"(a));
+    if constexpr (H == 1 && NEG == 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(s), "v"(c), "v"(a));
+    return d;
+}
+// a + (NEG ? -1 : 1) * (-i c)
+template <int NEG> __device__ __forceinline__ v2f pk_rot(v2f c, v2f a) {
+    v2f d;
+    if constexpr (NEG == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(c));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(d) : "v"(a), "v"(c));
+    return d;
+}
+// forward radix-4 on (a, gb b, gc c, gd d); the scales are halves HB/HC/HD of the pairs pb/pc/pd; rd = gd/gb.  8 instr.
+template <int HB, int HC, int HD> __device__ __forceinline__ void dft4p(v2f &a, v2f &b, v2f &c, v2f &d, v2f pb, v2f pc, v2f pd) {
+    const v2f t0 = pk_sfma<HC, 0>(pc, c, a), t1 = pk_sfma<HC, 1>(pc, c, a);
+    const v2f t2 = pk_sfma<HD, 0>(pd, d, b), t3 = pk_sfma<HD, 1>(pd, d, b);
+    a = pk_sfma<HB, 0>(pb, t2, t0);
+    c = pk_sfma<HB, 1>(pb, t2, t0);
+    b = pk_srot<HB, 0>(pb, t3, t1);
+    d = pk_srot<HB, 1>(pb, t3, t1);
+}
+__device__ __forceinline__ void dft4p_plain(v2f &a, v2f &b, v2f &c, v2f &d) {
+    const v2f t0 = a + c, t1 = a - c, t2 = b + d, t3 = b - d;
+    a = t0 + t2;
+    c = t0 - t2;
+    b = pk_rot<0>(t3, t1);
+    d = pk_rot<1>(t3, t1);
+}
+// packed constants of a radix-16 pass: p[j >> 1] half j & 1 holds Tw16::f[j]
+struct Tw16p {
+    v2f p[20];
+};
+__device__ __forceinline__ void pack_tw16(Tw16p &o, const Tw16 &w) {
+#pragma unroll
+    for (int i = 0; i < 20; ++i) o.p[i] = (v2f){w.f[2 * i], w.f[2 * i + 1]};
+}
+// K0 = (C16, C8)  K1 = (S16/C16, S16)  K2 = (-C8, -C16/S16)  K3 = (T16, T316): the W16 constants, kept in VGPR pairs
+// (a VALU source that is an SGPR issues at half rate)
+struct K16p {
+    v2f k0, k1, k2, k3;
+};
+__device__ __forceinline__ K16p make_k16p() {
+    K16p k;
+    k.k0 = (v2f){SP_C16, SP_C8};
+    k.k1 = (v2f){SP_S16 / SP_C16, SP_S16};
+    k.k2 = (v2f){-SP_C8, -SP_C16 / SP_S16};
+    k.k3 = (v2f){SP_T16, SP_T316};
+    asm volatile("" : "+v"(k.k0), "+v"(k.k1), "+v"(k.k2), "+v"(k.k3));
+    return k;
+}
+#define SP_TWP(w, j) (w).p[(j) >> 1]
+#define SP_TWH(j) ((j) & 1)
+template <bool TWD> __device__ __forceinline__ void dft16p(cf (&xc)[16], const Tw16p &w, const K16p &k) {
+    v2f x[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) x[s] = to_v2f(xc[s]);
+    if constexpr (TWD) {
+        // x (1 - i tau) = x + tau (-i x)
+#define SP_RT(s) x[s] = pk_srot<SP_TWH(Tw16::TAU + s - 1), 0>(SP_TWP(w, Tw16::TAU + s - 1), x[s], x[s]);
+        SP_RT(1) SP_RT(2) SP_RT(3) SP_RT(4) SP_RT(5) SP_RT(6) SP_RT(7) SP_RT(8) SP_RT(9) SP_RT(10) SP_RT(11) SP_RT(12)
+        SP_RT(13) SP_RT(14) SP_RT(15)
+#undef SP_RT
+#define SP_G1(b)                                                                                                     \
+    dft4p<SP_TWH(Tw16::RB + b), SP_TWH(Tw16::RC + b), SP_TWH(Tw16::RD + b)>(x[b], x[b + 4], x[b + 8], x[b + 12],     \
+                                                                           SP_TWP(w, Tw16::RB + b), SP_TWP(w, Tw16::RC + b), \
+                                                                           SP_TWP(w, Tw16::RD + b));
+        SP_G1(0) SP_G1(1) SP_G1(2) SP_G1(3)
+#undef SP_G1
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dft4p_plain(x[b], x[b + 4], x[b + 8], x[b + 12]);
+    }
+    // x[4c+b] = Y[b][c] (pending scale g[b]); rotate by W16^{bc} / K_bc
+    x[5] = pk_srot<0, 0>(k.k3, x[5], x[5]);        // W16^1 = C16 (1 - i tan(pi/8))
+    x[9] = pk_rot<0>(x[9], x[9]);                  // W16^2 = C8 (1 - i)
+    x[13] = pk_srot<1, 0>(k.k3, x[13], x[13]);     // W16^3 = S16 (1 - i tan(3pi/8))
+    x[6] = pk_rot<0>(x[6], x[6]);                  // W16^2
+    x[10] = pk_rot<0>(x[10], (v2f){0.f, 0.f});     // W16^4 = -i
+    x[14] = pk_rot<1>(x[14], x[14]);               // W16^6 = -C8 (1 + i)
+    x[7] = pk_srot<1, 0>(k.k3, x[7], x[7]);        // W16^3
+    x[11] = pk_rot<1>(x[11], x[11]);               // W16^6
+    x[15] = pk_srot<0, 0>(k.k3, x[15], x[15]);     // W16^9 = -C16 (1 - i tan(pi/8))
+    if constexpr (TWD) {
+#define SP_G2(c)                                                                                                     \
+    dft4p<SP_TWH(Tw16::S1 + c), SP_TWH(Tw16::S2 + c), SP_TWH(Tw16::S3 + c)>(x[4 * c], x[4 * c + 1], x[4 * c + 2], x[4 * c + 3], \
+                                                                           SP_TWP(w, Tw16::S1 + c), SP_TWP(w, Tw16::S2 + c), \
+                                                                           SP_TWP(w, Tw16::S3 + c));
+        SP_G2(0) SP_G2(1) SP_G2(2) SP_G2(3)
+#undef SP_G2
+    } else {
+        dft4p_plain(x[0], x[1], x[2], x[3]);
+        dft4p<0, 1, 0>(x[4], x[5], x[6], x[7], k.k0, k.k0, k.k1);             // rb = C16, rc = C8, rd = S16/C16
+        {
+            // rb = C8, rc = 1, rd = -1
+            const v2f t0 = x[8] + x[10], t1 = x[8] - x[10], t2 = x[9] - x[11], t3 = x[9] + x[11];
+            x[8] = pk_sfma<1, 0>(k.k0, t2, t0);
+            x[10] = pk_sfma<1, 1>(k.k0, t2, t0);
+            x[9] = pk_srot<1, 0>(k.k0, t3, t1);
+            x[11] = pk_srot<1, 1>(k.k0, t3, t1);
+        }
+        dft4p<1, 0, 1>(x[12], x[13], x[14], x[15], k.k1, k.k2, k.k2);         // rb = S16, rc = -C8, rd = -C16/S16
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xc[s] = to_cf(x[s]);
+    cf t;
+#define SP_SWAP(i, j) t = xc[i]; xc[i] = xc[j]; xc[j] = t;
+    SP_SWAP(1, 4) SP_SWAP(2, 8) SP_SWAP(3, 12) SP_SWAP(6, 9) SP_SWAP(7, 13) SP_SWAP(11, 14)
+#undef SP_SWAP
+}
+
 // per-thread constants of a twiddled radix-16 pass from the forward twiddles wv[s-1] = exp(-i s phi), s = 1..15
 __device__ __forceinline__ void make_tw16(Tw16 &w, const cf (&wv)[15]) {
     float g[16];
@@ -194,7 +329,11 @@ __device__ __forceinline__ void make_tw16(Tw16 &w, const cf (&wv)[15]) {
 }
 
 // SP_ABLATE (diagnostic builds only, results wrong): bit 0 = skip the radix-16 butterflies, bit 1 = skip the LDS
-// exchanges (and their barriers), bit 2 = skip the inter-pass twiddles, bit 3 = no global loads in the carry loop
+// exchanges (and their barriers), bit 2 = skip the inter-pass twiddles, bit 3 = no global loads in the carry loop, bit 4 = the loop's loads all hit L2
+// SP_PACKED=1: radix-16 butterflies in packed fp32 (v_pk_*_f32); 0: the scalar FMA form
+#ifndef SP_PACKED
+#define SP_PACKED 0
+#endif
 // SP_DIAG_SHARETW (diagnostic, results wrong): every twiddled radix-16 pass uses the first pass's constants
 #ifndef SP_DIAG_SHARETW
 #define SP_DIAG_SHARETW 0
@@ -240,11 +379,21 @@ template <int N> struct WgFft {
     static constexpr int R = PL::R, T = PL::T, NP = PL::NP;
     static constexpr int N16 = PL::NP16 > 1 ? PL::NP16 - 1 : 0;          // twiddled radix-16 passes
     static constexpr int NTR = (N >= 16 && PL::REM > 1) ? (R / PL::REM) * (PL::REM - 1) : 0;   // remainder-pass twiddles
+#if SP_PACKED
+    Tw16p t16[N16 > 0 ? N16 : 1];
+    K16p k16;
+#else
     Tw16 t16[N16 > 0 ? N16 : 1];
+#endif
     cf twr[NTR > 0 ? NTR : 1];
 
     // table[m] = exp(-2 pi i m / N), m = 0..N-1
-    __device__ __forceinline__ void load_twiddles(const cf *__restrict__ table, int tid) { load_tw<1>(table, tid); }
+    __device__ __forceinline__ void load_twiddles(const cf *__restrict__ table, int tid) {
+#if SP_PACKED
+        k16 = make_k16p();
+#endif
+        load_tw<1>(table, tid);
+    }
 
     template <int P> __device__ __forceinline__ void load_tw(const cf *__restrict__ table, int tid) {
         if constexpr (P < NP) {
@@ -254,7 +403,13 @@ template <int N> struct WgFft {
                 cf wv[15];
 #pragma unroll
                 for (int s = 1; s < 16; ++s) wv[s - 1] = table[e * s];
+#if SP_PACKED
+                Tw16 w1;
+                make_tw16(w1, wv);
+                pack_tw16(t16[P - 1], w1);
+#else
                 make_tw16(t16[P - 1], wv);
+#endif
             } else {
 #pragma unroll
                 for (int u = 0; u < NB; ++u) {
@@ -285,11 +440,16 @@ template <int N> struct WgFft {
             for (int s = 0; s < r; ++s) x[s] = v[u + s * NB];
             if constexpr (r == 16) {
                 if constexpr (!(SP_ABLATE & 1)) {
+#if SP_PACKED
+                    if constexpr (P > 0 && !(SP_ABLATE & 4)) dft16p<true>(x, t16[SP_DIAG_SHARETW ? 0 : P - 1], k16);
+                    else dft16p<false>(x, t16[0], k16);
+#else
                     if constexpr (P > 0 && !(SP_ABLATE & 4)) {
                         dft16s<true>(x, t16[SP_DIAG_SHARETW ? 0 : P - 1]);
                     } else {
                         dft16s<false>(x, t16[0]);
                     }
+#endif
                 }
             } else {
                 if constexpr (P > 0 && !(SP_ABLATE & 4)) {

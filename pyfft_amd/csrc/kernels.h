@@ -330,7 +330,31 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
 #pragma unroll
         for (int t = 0; t < C::R; ++t) raw[t] = raw[t] - mu;
     }
-    for (int64_t i = 0; i < trips; ++i) {
+    // new slots of frame gq (clamped at the end of the signal; unused then)
+    auto issue = [&](cf (&dst)[SHIFT], int64_t gq) __attribute__((always_inline)) {
+        int64_t gn = gq < nframes ? gq : last;
+        if constexpr (SP_ABLATE & 16) gn = blockIdx.x & 7;          // diagnostic: every load hits L2 (8 distinct frames)
+        if constexpr (UNI && !(SP_ABLATE & 8)) {
+            // one group per workgroup: the frame base is uniform -> scalar base pointer + 32-bit lane offset
+            const int64_t ubase = gn * hop + (int64_t)C::T * KEEP;
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) {
+                const unsigned off = (unsigned)(tid + C::T * s);
+                if (CPLX) dst[s] = (reinterpret_cast<const cf *>(x) + ubase)[off];
+                else dst[s] = mk((reinterpret_cast<const float *>(x) + ubase)[off], 0.f);
+            }
+        } else {
+            const int64_t base = gn * hop + tid + (int64_t)C::T * KEEP;
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) {
+                if constexpr (SP_ABLATE & 8) dst[s] = raw[s] + mu;  // diagnostic: no global loads in the loop
+                else dst[s] = load_sample(x, base + C::T * s, CPLX);
+            }
+        }
+    };
+    // one frame: window, transform, accumulate; `fill` receives a prefetch (issued once v is formed, so that the
+    // incoming samples can take over the registers of the slots that just died), `take` holds the new slots of frame g+1
+    auto body = [&](int64_t i, cf (&fill)[SHIFT], int64_t fill_frame, cf (&take)[SHIFT]) __attribute__((always_inline)) {
         const int64_t g = g0 + i;
         const float keep = (UNI || g < nframes) ? 1.f : 0.f;
         if (ONEPASS) {
@@ -340,30 +364,7 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
         cf v[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = w[t] * raw[t];
-        // prefetch the SHIFT new slots of frame g+1 (clamped at the end of the signal; unused then).  Issued after
-        // v is formed so that the incoming samples can take over the registers of the slots that just died.
-        cf nx[SHIFT];
-        {
-            const int64_t gn = g + 1 < nframes ? g + 1 : last;
-            if constexpr (UNI && !(SP_ABLATE & 8)) {
-                // one group per workgroup: the frame base is uniform -> scalar base pointer + 32-bit lane offset, no
-                // 64-bit VALU address arithmetic in the loop
-                const int64_t ubase = gn * hop + (int64_t)C::T * KEEP;
-#pragma unroll
-                for (int s = 0; s < SHIFT; ++s) {
-                    const unsigned off = (unsigned)(tid + C::T * s);
-                    if (CPLX) nx[s] = (reinterpret_cast<const cf *>(x) + ubase)[off];
-                    else nx[s] = mk((reinterpret_cast<const float *>(x) + ubase)[off], 0.f);
-                }
-            } else {
-                const int64_t base = gn * hop + tid + (int64_t)C::T * KEEP;
-#pragma unroll
-                for (int s = 0; s < SHIFT; ++s) {
-                    if constexpr (SP_ABLATE & 8) nx[s] = raw[s] + mu;      // diagnostic: no global loads in the loop
-                    else nx[s] = load_sample(x, base + C::T * s, CPLX);
-                }
-            }
-        }
+        issue(fill, fill_frame);
         if (SP_CARRY_NBUF == 2) {
             // ping-pong exchange images: with an odd number of exchanges per transform the roles swap every frame
             cf *lds_b = lds + C::FPW * C::LDS_PER;
@@ -378,11 +379,17 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
             if (UNI) acc[t] = fmaf(v[t].y, v[t].y, fmaf(v[t].x, v[t].x, acc[t]));
             else acc[t] += keep * cnorm(v[t]);
         }
-        // advance one hop: rename registers, detrend the samples that just arrived
+        // advance one hop: rename registers, detrend the samples that arrived
 #pragma unroll
         for (int t = 0; t < KEEP; ++t) raw[t] = raw[t + SHIFT];
 #pragma unroll
-        for (int s = 0; s < SHIFT; ++s) raw[KEEP + s] = nx[s] - mu;
+        for (int s = 0; s < SHIFT; ++s) raw[KEEP + s] = take[s] - mu;
+    };
+    // (prefetching two frames ahead -- a ring of two buffers, the loop unrolled by two -- measured no faster: the cost
+    //  of streaming from HBM, 0.52 -> 0.64 ms against the same loads hitting L2, is not exposed latency)
+    for (int64_t i = 0; i < trips; ++i) {
+        cf nx[SHIFT];
+        body(i, nx, g0 + i + 1, nx);
     }
 #pragma unroll
     for (int t = 0; t < C::R; ++t) partial[gid * N + tid + C::T * t] = acc[t];
