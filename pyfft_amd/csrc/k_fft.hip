@@ -12,6 +12,22 @@ int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int invers
     return 0;
 }
 
+// one workgroup per FPW rows; the grid is padded to a multiple of 8 blocks (surplus blocks exit at once)
+int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_t in_rs, int64_t in_es, int64_t out_rs,
+                       int64_t out_es, int conj_in, int conj_out, float scale, const Xf &xf, BigTw bt) {
+    if (xf.blue) return -1;
+    const int fpw = fpw_of(xf.L);
+    if (batch % fpw) return -1;
+    int64_t blocks = batch / fpw;
+    blocks = (blocks + 7) / 8 * 8;
+#define M_(XT)                                                                                        \
+    hipLaunchKernelGGL((k_fft_strided<XT::L>), dim3((unsigned)blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, \
+                       batch, in_rs, in_es, out_rs, out_es, conj_in, conj_out, scale, xf.tb, bt, 1);
+    SP_DISPATCH_P(xf, M_)
+#undef M_
+    return 0;
+}
+
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out) {
     const int blocks = strided_blocks(xf.L, batch, c.ncu);
 #define M_(XT)                                                                                        \

@@ -176,6 +176,46 @@ __global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in,
 }
 
 // ------------------------------------------------------------------------------------------
+// Strided form for the two-pass long transform (N = N1 N2 > 8192): element i of row b sits at in[b*in_rs + i*in_es] and
+// goes to out[b*out_rs + i*out_es], so a "row" can be a COLUMN of a row-major matrix and the three explicit transposes
+// of the four-step algorithm disappear (2 passes x 16 B/point instead of 5).  A column read touches one 8-byte element
+// per 128-byte line, so the lines must be shared in L2: consecutive workgroups of one XCD (blockIdx = xcd + 8 j: the
+// hardware deals workgroups to the 8 XCDs in turn) take ADJACENT columns, which are launched and run close together.
+// conj_in / conj_out + scale implement the inverse as conj(fft(conj(.)))/N across the two passes; bt (optional) is the
+// inter-pass twiddle W_N^{b i}.  Power-of-two lengths.
+// ------------------------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restrict__ in, cf *__restrict__ out, int64_t batch,
+                                                               int64_t in_rs, int64_t in_es, int64_t out_rs, int64_t out_es,
+                                                               int conj_in, int conj_out, float scale, XfTables tb, BigTw bt,
+                                                               int remap) {
+    using X = XfPow2<N>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
+    const float si = conj_in ? -1.f : 1.f, so = conj_out ? -1.f : 1.f;
+    // blocks per XCD = gridDim.x / 8 (the launcher makes the grid a multiple of 8): XCD x owns a contiguous range of rows
+    const int64_t per_xcd = gridDim.x / 8;
+    const int64_t gid = remap ? (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    const int64_t b = gid * C::FPW + grp;
+    if (b >= batch) return;                       // whole groups only (batch is a multiple of FPW); no barrier is skipped
+    cf v[C::R];                                   // by a partial workgroup because FPW divides the grid's row count
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) v[t] = in[b * in_rs + (int64_t)(tid + C::T * t) * in_es];
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, si * v[t].y);
+    xf.fwd(v, lds, tid, N);
+    if (bt.lo != nullptr) {
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int64_t m = b * (int64_t)(tid + C::T * t);
+            v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) out[b * out_rs + (int64_t)(tid + C::T * t) * out_es] = mk(scale * v[t].x, so * scale * v[t].y);
+}
+
+// ------------------------------------------------------------------------------------------
 // A3+A4  fused Welch PSD (fft_analysis.py:2156-2176 loop + :1946 |X|^2 + :1980 mean), generic form.
 // Each group owns frames [gid*fpg, (gid+1)*fpg); |X|^2 is accumulated in registers over the
 // run, one partial spectrum per group goes to HBM.  trend[4] (device) is removed before the window

@@ -60,6 +60,10 @@ inline RunPart run_partition_2d(int L, int64_t nframes, int ncu, int ny) {
     if (target < 8 * fpw) target = 8 * fpw;
     int64_t f = (nframes + target - 1) / target;
     if (f < 1) f = 1;
+    if (const char *e = getenv("SP_FPG")) {               // experiments: frames per group
+        const int64_t v = atoll(e);
+        if (v > 0) f = v;
+    }
     const int64_t G = (nframes + f - 1) / f;
     RunPart r;
     r.fpg = f;
@@ -79,6 +83,8 @@ inline int strided_blocks(int L, int64_t items, int ncu) {
 // every launcher returns 0 or -1 (unsupported L); kernel launch errors surface through hipGetLastError
 int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf,
                    BigTw bt = BigTw{nullptr, nullptr, 0});
+int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_t in_rs, int64_t in_es, int64_t out_rs,
+                       int64_t out_es, int conj_in, int conj_out, float scale, const Xf &xf, BigTw bt);
 // elementwise / transpose pieces of the long paths (k_fft.hip)
 int launch_transpose_c(LaunchCtx c, const cf *in, cf *out, int64_t rows, int64_t cols, int conj, float scale);
 int launch_pack_real(LaunchCtx c, const float *x, int64_t n_in, const double *mean, int64_t L, cf *out);

@@ -115,3 +115,19 @@ def test_hilbert_edge_shapes(P):
     np.testing.assert_allclose(P.hilbert(np.arange(5.0)), O.hilbert(np.arange(5.0)), atol=2e-6)     # odd quirk
     with pytest.raises(NotImplementedError):
         P.hilbert(np.ones(8) + 1j)
+
+
+def test_long_fft_two_pass_option_matches(monkeypatch):
+    """SP_BIGFFT_2PASS=1 (strided two-pass long transform, an option that measured slower) == the default five-pass form"""
+    from pyfft_amd import engine as E
+    rng = np.random.default_rng(21)
+    for n in (1 << 14, 1 << 17):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        a = E.fft(x)
+        ai = E.ifft(a)
+        monkeypatch.setenv("SP_BIGFFT_2PASS", "1")
+        b = E.fft(x)
+        bi = E.ifft(b)
+        monkeypatch.delenv("SP_BIGFFT_2PASS")
+        assert np.max(np.abs(a - b)) <= 2e-6 * np.abs(a).max()
+        assert np.max(np.abs(bi - x)) <= 3e-6 * np.abs(x).max() and np.max(np.abs(ai - x)) <= 3e-6 * np.abs(x).max()
