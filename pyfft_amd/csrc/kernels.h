@@ -563,15 +563,33 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
         // the shard's own mean (what k_op_total computes for the split ABI), here without the extra launch:
         // sum_{i<nmean}(x[i] - mu0) = all block sums + head blocks +/- the ragged end
         double a = 0, b = 0;
-        for (int j = threadIdx.x; j < H; j += C::WG) {
-            a += Sl[2 * j];
-            b += Sl[2 * j + 1];
-        }
+        // H <= N and head < N: fixed trip counts with masks, so that all loads of a thread are in flight together
+        // (this workgroup is one latency chain; with data-dependent loops it cost 28 us per step)
+        constexpr int NIT = N / C::WG > 0 ? N / C::WG : 1;
         const int64_t head = (int64_t)(r - 1) * H, cov = (M + r - 1) * (int64_t)H;
-        for (int64_t i = threadIdx.x; i < head; i += C::WG) {
-            const cf s = load_sample(x, i, CPLX) - mu;
-            a += s.x;
-            b += s.y;
+        {
+            double sa[NIT], sb[NIT];
+            cf hv[NIT];
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                const int j = (int)threadIdx.x + q * C::WG;
+                const int jc = j < H ? j : 0;
+                sa[q] = Sl[2 * jc];
+                sb[q] = Sl[2 * jc + 1];
+                hv[q] = load_sample(x, j < head ? j : 0, CPLX);
+            }
+#pragma unroll
+            for (int q = 0; q < NIT; ++q) {
+                const int j = (int)threadIdx.x + q * C::WG;
+                if (j < H) {
+                    a += sa[q];
+                    b += sb[q];
+                }
+                if (j < head) {
+                    a += (double)(hv[q].x - mu.x);
+                    b += (double)(hv[q].y - mu.y);
+                }
+            }
         }
         const int64_t lo = nmean > cov ? cov : nmean, hi = nmean > cov ? nmean : cov;
         const double sgn = nmean > cov ? 1.0 : -1.0;
