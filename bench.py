@@ -8,8 +8,9 @@
 
 A "step" = one pass of the hot path over one batch of synthetic input: every rank runs the fused Welch PSD
 (global-mean detrend + window + overlapped FFT + |X|^2 + segment average, one pass over the samples) over its own
-2^28-sample segment of the stream, device-resident; at N>1 the shards' sample sums (2 doubles) and then their 4096-bin
-accumulators are summed with RCCL all-reduces (the only exchange the path has).  Weak scaling: per-GPU work is
+2^28-sample segment of the stream, device-resident; at N>1 the shards' additive states (|X|^2 accumulator + what is
+needed to apply the mean of the whole stream: 5*4096+8 doubles) are summed with ONE RCCL all-reduce (the only
+exchange the path has).  Weak scaling: per-GPU work is
 fixed, value = all samples / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.  Extra objects: roofline (dominant kernel k_welch, HIP events on the launch
@@ -108,8 +109,7 @@ def main():
 
     def step():
         # the whole hot path: global-mean detrend (fft_analysis.py:2148) + window + overlapped FFT + |X|^2 + segment
-        # average, in ONE pass over the samples; at N>1: all_reduce(2 doubles) for the stream mean, then
-        # all_reduce(nfft doubles) of the accumulator (pyfft_amd/dist.py)
+        # average, in ONE pass over the samples; at N>1: one all_reduce of the shard states (pyfft_amd/dist.py)
         if world == 1:
             return E.welch_psd(x, win, hop, M_local, detrend=True, sided=E.SIDED_TWO, scale=scale)
         return welch_psd_sharded(x, win, plan, scale=scale, sided=E.SIDED_TWO)
@@ -162,7 +162,7 @@ def main():
         "config": {"workload": "Welch PSD, 2^%d complex64 samples per GPU, nfft=%d periodic Hann, hop=%d, "
                                "global mean detrend, two-sided" % (args.log2n, nfft, hop),
                    "samples_per_gpu": S, "frames_per_gpu": M_local, "settle_steps": args.settle_steps, "parallelism": "segment-sharded x%d, "
-                   "one RCCL all-reduce of the %d-bin accumulator" % (world, nfft)},
+                   "one RCCL all-reduce of the shard state (%d doubles)" % (world, 5 * nfft + 8)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": TRAFFIC_BYTES_PER_LAUNCH.get((args.log2n, nfft)) if world == 1 else None,

@@ -89,6 +89,15 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
 int sp_welch_accum(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
                    int64_t nmean, double *sum_out, int mem);
 int sp_welch_finish(const double *mean, int64_t frames_total, int sided, double scale, double *pxx_out, int mem);
+/*      One-collective form of the same split.  sp_welch_export leaves this shard's ADDITIVE state in
+ *      state[5*nfft + 8] (doubles): sum|X|^2, sum X and conj(mu0) sum X per bin (spectra taken against the shard's
+ *      own mean estimate mu0), M mu0, M |mu0|^2, the sum of its nmean own samples, M and nmean.  The states of all
+ *      shards are summed with ONE all-reduce and sp_welch_apply turns the sum into the PSD of the whole stream
+ *      detrended by its global mean (same output conventions as sp_welch_finish). */
+int sp_welch_export(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop,
+                    int64_t nframes, int64_t nmean, double *state, int mem);
+int sp_welch_apply(const double *state, const float *win, int nfft, int64_t frames_total, int sided, double scale,
+                   double *pxx_out, int mem);
 
 /* ---- A5: fft_pwelch numeric core (fft_analysis.py:339-446): reference x against nch
  *      channels y[c][0:nsig] (channel-major, row stride y_ld samples).

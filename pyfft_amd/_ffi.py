@@ -37,6 +37,8 @@ SIGNATURES = {
     "sp_welch_psd": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i, _d, _d, _i, _d, _vp, _i]),
     "sp_welch_accum": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp, _i]),
     "sp_welch_finish": (_i, [_vp, _i64, _i, _d, _vp, _i]),
+    "sp_welch_export": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp, _i]),
+    "sp_welch_apply": (_i, [_vp, _vp, _i, _i64, _i, _d, _vp, _i]),
     "sp_welch_csd": (_i, [_vp, _vp, _i, _i64, _i, _i64, _vp, _i, _i, _i64, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _i]),
     "sp_csd_matrix": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i, _i64, _i, _d, _vp, _i]),
     "sp_csd_matrix_means": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i, _i64, _vp, _d, _vp, _i]),

@@ -120,14 +120,21 @@ int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, 
     return 0;
 }
 
-// c -> B = FFT(w c) -> combine, one workgroup
+// c -> B = FFT(w c) -> combine, one workgroup.  export_state: write the shard's additive state instead (out = state)
 int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, OnePass st,
                      const double *mean_in, int64_t nmean, const Xf &xf, int hop, int64_t nframes, cf *, const cf *Wf,
-                     int sided, double scale, double *out) {
+                     int sided, double scale, double *out, bool export_state) {
     const int H = hop, r = xf.L / H;
 #define FIN_(NN)                                                                                      \
     case NN:                                                                                          \
-        if (cplx)                                                                                     \
+        if (export_state) {                                                                           \
+            if (cplx)                                                                                 \
+                hipLaunchKernelGGL((k_op_finish<NN, true, true>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, \
+                                   x, trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out); \
+            else                                                                                      \
+                hipLaunchKernelGGL((k_op_finish<NN, false, true>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, \
+                                   x, trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out); \
+        } else if (cplx)                                                                              \
             hipLaunchKernelGGL((k_op_finish<NN, true>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
                                trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out); \
         else                                                                                          \
@@ -139,6 +146,11 @@ int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, 
         default: return -1;
     }
 #undef FIN_
+    return 0;
+}
+
+int launch_op_apply(LaunchCtx c, const double *state, const cf *Wf, int n, int sided, double scale, double *out) {
+    hipLaunchKernelGGL(k_op_apply, dim3((n + 255) / 256), dim3(256), 0, c.stream, state, Wf, n, sided, scale, out);
     return 0;
 }
 

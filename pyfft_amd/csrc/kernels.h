@@ -539,7 +539,10 @@ static __global__ __launch_bounds__(1024) void k_op_total(const void *__restrict
 // one workgroup: c[n] = sum_g x_g[n] rebuilt from the block sums and the few edge blocks, B = FFT(w c) = sum_g X_g,
 // then out[slot] = scale * doubling * (A[k] - 2 Re(conj(d W[k]) B[k]) + M |d W[k]|^2) with d = mean - mu0.
 // mean_in != null (the caller's global mean) overrides the shard's own delta.
-template <int N, bool CPLX>
+// EXPORT: instead of the finished spectrum, write this shard's additive state (see sp_welch_export) into `out`:
+//   out[0..N) = A[k]   out[N..3N) = B[k] (re, im)   out[3N..5N) = conj(mu0) B[k]
+//   out[5N..5N+8) = M mu0 (re, im), M |mu0|^2, sum of the nmean own samples (re, im), M, nmean, 0
+template <int N, bool CPLX, bool EXPORT = false>
 static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *__restrict__ x, const float *__restrict__ trend,
                                                                     const float *__restrict__ win,
                                                                     const double *__restrict__ Sl,
@@ -553,10 +556,11 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
     (void)n;
     const cf mu = mk(trend[0], trend[1]);
     double dr, di;
-    if (mean_in) {
+    double tot_r = 0.0, tot_i = 0.0;
+    if (!EXPORT && mean_in) {
         dr = mean_in[0] - (double)trend[0];
         di = mean_in[1] - (double)trend[1];
-    } else if (dlt_local) {
+    } else if (!EXPORT && dlt_local) {
         dr = dlt_local[0];
         di = dlt_local[1];
     } else {
@@ -609,8 +613,10 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
             }
             __syncthreads();
         }
-        dr = red[0] / (double)nmean;
-        di = red[C::WG] / (double)nmean;
+        tot_r = red[0];
+        tot_i = red[C::WG];
+        dr = tot_r / (double)nmean;
+        di = tot_i / (double)nmean;
         __syncthreads();
     }
     cf v[C::R];
@@ -633,6 +639,33 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
         v[t] = (grp == 0) ? mk((float)(wn * a), (float)(wn * b)) : mk(0.f, 0.f);
     }
     xf.fwd(v, lds, tid, N);
+    if constexpr (EXPORT) {
+        if (grp == 0) {
+            const double mr = (double)mu.x, mi = (double)mu.y;
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int k = tid + C::T * t;
+                const double br = (double)v[t].x, bi = (double)v[t].y;
+                out[k] = A[k];
+                out[N + 2 * k] = br;
+                out[N + 2 * k + 1] = bi;
+                out[3 * N + 2 * k] = mr * br + mi * bi;          // conj(mu0) B
+                out[3 * N + 2 * k + 1] = mr * bi - mi * br;
+            }
+            if (threadIdx.x == 0) {
+                double *sc = out + 5 * N;
+                sc[0] = (double)M * mr;
+                sc[1] = (double)M * mi;
+                sc[2] = (double)M * (mr * mr + mi * mi);
+                sc[3] = tot_r + (double)nmean * mr;
+                sc[4] = tot_i + (double)nmean * mi;
+                sc[5] = (double)M;
+                sc[6] = (double)nmean;
+                sc[7] = 0.0;
+            }
+        }
+        return;
+    }
     if (grp == 0) {
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
@@ -645,6 +678,27 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
             out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
         }
     }
+}
+
+// The all-reduced (summed over shards) state of k_op_finish<EXPORT> -> the PSD of the whole stream, detrended by the
+// global mean mu = S / n:  P[k] = A - 2 Re(conj(W) (conj(mu) B - C)) + |W|^2 (|mu|^2 M - 2 Re(conj(mu) S1) + S2)
+// (each shard's sum |X - (mu - mu0_r) W|^2, expanded so that only sums over shards appear).
+static __global__ __launch_bounds__(256) void k_op_apply(const double *__restrict__ st, const cf *__restrict__ Wf, int n,
+                                                         int sided, double scale, double *__restrict__ out) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int slot = bin_slot(k, n, sided);
+    if (slot < 0) return;
+    const double *sc = st + 5 * (int64_t)n;
+    const double Mt = sc[5], nt = sc[6];
+    const double mr = sc[3] / nt, mi = sc[4] / nt;
+    const double br = st[n + 2 * k], bi = st[n + 2 * k + 1], cr = st[3 * n + 2 * k], ci = st[3 * n + 2 * k + 1];
+    const double dr = mr * br + mi * bi - cr, di = mr * bi - mi * br - ci;            // conj(mu) B - C
+    const double wr = Wf[k].x, wi = Wf[k].y;
+    const double cross = wr * dr + wi * di;                                            // Re(conj(W) D)
+    const double s = (mr * mr + mi * mi) * Mt - 2.0 * (mr * sc[0] + mi * sc[1]) + sc[2];
+    const double p = st[k] - 2.0 * cross + (wr * wr + wi * wi) * s;
+    out[slot] = p * scale * (bin_doubled(k, n, sided) ? 2.0 : 1.0);
 }
 
 // mean estimate mu0: 64 contiguous runs of <= 1024 samples spread over the whole signal (robust to drift, and each

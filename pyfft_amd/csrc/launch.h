@@ -104,7 +104,8 @@ int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, 
                      int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st, double *sum_out);
 int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, OnePass st,
                      const double *mean_in, int64_t nmean, const Xf &xf, int hop, int64_t nframes, cf *cw, const cf *Wf,
-                     int sided, double scale, double *out);
+                     int sided, double scale, double *out, bool export_state = false);
+int launch_op_apply(LaunchCtx c, const double *state, const cf *Wf, int n, int sided, double scale, double *out);
 int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int sided, double scale, double *out,
                         int sym = 0);
 int launch_welch_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,

@@ -486,6 +486,19 @@ int dev_fft_any(const cf *in, cf *out, int64_t n, int64_t batch, int inverse) {
 
 
 // ---- one-pass Welch: accumulate, then finish with a (possibly global) mean ------------------------
+// Wf = FFT(window) on the device, cached under the window's content
+int get_window_spectrum(const float *win, int nfft, const Xf &xf, void **Wf_d) {
+    bool fresh = false;
+    if (get_table_keyed(3, win, sizeof(float) * (size_t)nfft, nullptr, sizeof(cf) * (size_t)nfft, Wf_d, &fresh)) return -1;
+    if (fresh) {
+        std::vector<cf> wc((size_t)nfft);
+        for (int i = 0; i < nfft; ++i) wc[(size_t)i] = make_float2(win[i], 0.f);
+        HIPCHK(hipMemcpy(*Wf_d, wc.data(), sizeof(cf) * (size_t)nfft, hipMemcpyHostToDevice));
+        LAUNCHCHK(launch_fft_c2c(lc(), (const cf *)*Wf_d, (cf *)*Wf_d, 1, 0, xf));
+    }
+    return 0;
+}
+
 // want_sum: also produce the shard's plain sample sum (split ABI, one more tiny launch); without it the finish kernel
 // derives the shard mean itself
 int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
@@ -498,16 +511,8 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     if (nmean < 1 || nmean > nsig) return fail("sp_welch_accum: nmean must be in [1, nsig]");
     void *win_d;
     if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
-    // Wf = FFT(window), cached under the window's content
     void *Wf_d;
-    bool fresh = false;
-    if (get_table_keyed(3, win, sizeof(float) * (size_t)nfft, nullptr, sizeof(cf) * (size_t)nfft, &Wf_d, &fresh)) return -1;
-    if (fresh) {
-        std::vector<cf> wc((size_t)nfft);
-        for (int i = 0; i < nfft; ++i) wc[(size_t)i] = make_float2(win[i], 0.f);
-        HIPCHK(hipMemcpy(Wf_d, wc.data(), sizeof(cf) * (size_t)nfft, hipMemcpyHostToDevice));
-        LAUNCHCHK(launch_fft_c2c(lc(), (const cf *)Wf_d, (cf *)Wf_d, 1, 0, xf));
-    }
+    if (get_window_spectrum(win, nfft, xf, &Wf_d)) return -1;
     TrendBuf tb;
     if (get_trendbuf(1, &tb)) return -1;
     const RunPart rp = run_partition(xf.L, nframes, g.ncu);
@@ -835,6 +840,66 @@ int sp_welch_finish(const double *mean, int64_t frames_total, int sided, double 
         }
     }
     if (welch_finish_locked(mean_d, frames_total, sided, scale, out_d)) return -1;
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(pxx_out, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
+}
+
+int sp_welch_export(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+                    int64_t nmean, double *state, int mem) {
+    if (ensure_init()) return -1;
+    if (check_frames("sp_welch_export", nsig, nfft, hop, nframes)) return -1;
+    std::lock_guard<std::mutex> lk(g.mu);
+    const bool cplx = x_dtype == SP_DTYPE_C64;
+    const size_t esz = cplx ? 8 : 4;
+    const void *xd = x;
+    if (!mem) {
+        if (g.in0.ensure(esz * (size_t)nsig)) return -1;
+        HIPCHK(hipMemcpyAsync(g.in0.p, x, esz * (size_t)nsig, hipMemcpyHostToDevice, g.stream));
+        xd = g.in0.p;
+    }
+    if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, false)) return -1;
+    g_pend.valid = false;
+    const size_t nst = 5 * (size_t)nfft + 8;
+    double *st_d = state;
+    if (!mem) {
+        if (g.out0.ensure(sizeof(double) * nst)) return -1;
+        st_d = (double *)g.out0.p;
+    }
+    LAUNCHCHK(launch_op_finish(lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, nullptr, g_pend.nmean,
+                               g_pend.xf, g_pend.hop, g_pend.nframes, g_pend.cw, g_pend.Wf, SP_SIDED_RAW, 1.0, st_d, true));
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(state, st_d, sizeof(double) * nst, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
+}
+
+int sp_welch_apply(const double *state, const float *win, int nfft, int64_t frames_total, int sided, double scale,
+                   double *pxx_out, int mem) {
+    if (ensure_init()) return -1;
+    if (sided < 1 || sided > 3) return fail("sp_welch_apply: bad sided");
+    if (frames_total < 1) return fail("sp_welch_apply: frames_total must be positive");
+    std::lock_guard<std::mutex> lk(g.mu);
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
+    if (xf.blue) return fail("sp_welch_apply: power-of-two nfft only");
+    void *Wf_d;
+    if (get_window_spectrum(win, nfft, xf, &Wf_d)) return -1;
+    const int nb = nbins_host(nfft, sided);
+    const size_t nst = 5 * (size_t)nfft + 8;
+    const double *st_d = state;
+    double *out_d = pxx_out;
+    if (!mem) {
+        if (g.out0.ensure(sizeof(double) * (nst + (size_t)nb) + 64)) return -1;
+        double *sd = (double *)g.out0.p;
+        HIPCHK(hipMemcpyAsync(sd, state, sizeof(double) * nst, hipMemcpyHostToDevice, g.stream));
+        st_d = sd;
+        out_d = sd + nst;
+    }
+    LAUNCHCHK(launch_op_apply(lc(), st_d, (const cf *)Wf_d, nfft, sided, scale / (double)frames_total, out_d));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(pxx_out, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));

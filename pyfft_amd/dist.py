@@ -1,8 +1,8 @@
 """Segment-sharded Welch PSD / CSD matrix and channel-sharded reference-vs-channels CSD across the GPUs of one node: one process per GPU, torch.distributed (backend "nccl" =
 RCCL over xGMI).  The path shards by frames -- every rank owns a contiguous range of segments of one long stream
-plus a (nfft-hop)-sample halo -- and has exactly one real exchange: the averaged-PSD accumulator (nfft doubles,
-32 KiB at nfft=4096: latency-bound on any topology), preceded by a 2-double all-reduce of the sample sums so that the
-global-mean detrend (fft_analysis.py:2148) is the mean of the WHOLE stream, not of each shard.
+plus a (nfft-hop)-sample halo -- and has exactly one exchange: an all-reduce of the shards' additive state (the |X|^2
+accumulator plus what is needed to apply the mean of the WHOLE stream afterwards, fft_analysis.py:2148; 160 KiB at
+nfft=4096: latency-bound on any topology).
 
     plan = shard_plan(total_samples, nfft, hop, world, rank)
     x_local = stream[plan.first_sample : plan.first_sample + plan.nsamples]          # device resident
@@ -40,29 +40,45 @@ def shard_plan(total_samples, nfft, hop, world, rank):
 def _device_backend():
     from . import engine as E
 
-    def accum(x, win, hop, frames, nmean):
-        return E.welch_accum(x, win, hop, frames, nmean=nmean)
+    def export(x, win, hop, frames, nmean):
+        return E.welch_export(x, win, hop, frames, nmean=nmean)
 
-    def finish(nfft, mean, frames_total, sided, scale, like):
-        return E.welch_finish(nfft, mean, frames_total, sided=sided, scale=scale, like=like)
-    return accum, finish
+    def apply(state, win, frames_total, sided, scale):
+        return E.welch_apply(state, win, frames_total, sided=sided, scale=scale)
+    return export, apply
 
 
 def welch_psd_sharded(x_local, win, plan, scale=1.0, sided=2, group=None, backend=None):
-    """Welch PSD of the whole stream from this rank's shard (global-mean detrend).  Collectives: all_reduce(2 doubles),
-    all_reduce(nbins doubles).  `backend` = (accum, finish) callables; default: the HIP kernels.  With world == 1 no
-    collective is issued."""
+    """Welch PSD of the whole stream from this rank's shard (global-mean detrend) with ONE collective: every rank
+    exports its additive state (sum|X|^2, sum X, conj(mu0) sum X per bin against its own mean estimate mu0, plus a few
+    scalars: 5 nfft + 8 doubles, 160 KiB at nfft = 4096 -- latency-bound on any topology), the states are summed with
+    one all_reduce, and every rank applies the global mean to the sum.  `backend` = (export, apply) callables; default:
+    the HIP kernels (sp_welch_export / sp_welch_apply).  With world == 1 no collective is issued."""
     import torch
     import torch.distributed as dist
-    accum, finish = backend if backend is not None else _device_backend()
-    # each rank's own samples start at local index 0 (rank 0) / 0 too (its first frame starts at its first own sample)
-    s = accum(x_local, win, plan.hop, plan.frames, plan.own_samples)
+    export, apply = backend if backend is not None else _device_backend()
+    s = export(x_local, win, plan.hop, plan.frames, plan.own_samples)
     is_t = isinstance(s, torch.Tensor)
-    st = s if is_t else torch.from_numpy(np.asarray(s, dtype=np.float64))
+    st = s if is_t else torch.from_numpy(np.ascontiguousarray(s, dtype=np.float64))
     if plan.world > 1:
         dist.all_reduce(st, group=group)
-    mean = st / float(plan.total_samples)
-    p = finish(plan.nfft, mean if is_t else mean.numpy(), plan.frames_total, sided, scale, x_local)
+    return apply(st if is_t else st.numpy(), win, plan.frames_total, sided, scale)
+
+
+def welch_psd_sharded_two_step(x_local, win, plan, scale=1.0, sided=2, group=None):
+    """The same result with the older split (sp_welch_accum / sp_welch_finish): all_reduce(2 doubles) of the sample sums,
+    finish with the global mean, all_reduce(nbins doubles) of the finished shard spectra.  Two collectives; kept for the
+    C ABI's sake and A/B tests."""
+    import torch
+    import torch.distributed as dist
+    from . import engine as E
+    st = E.welch_accum(x_local, win, plan.hop, plan.frames, nmean=plan.own_samples)
+    is_t = isinstance(st, torch.Tensor)
+    stt = st if is_t else torch.from_numpy(np.asarray(st, dtype=np.float64))
+    if plan.world > 1:
+        dist.all_reduce(stt, group=group)
+    mean = stt / float(plan.total_samples)
+    p = E.welch_finish(plan.nfft, mean if is_t else mean.numpy(), plan.frames_total, sided=sided, scale=scale, like=x_local)
     pt = p if isinstance(p, torch.Tensor) else torch.from_numpy(np.asarray(p, dtype=np.float64))
     if plan.world > 1:
         dist.all_reduce(pt, group=group)

@@ -179,6 +179,45 @@ def welch_accum(x, win, hop, nframes, nmean=None):
     return out
 
 
+def welch_export(x, win, hop, nframes, nmean=None):
+    """One-collective form of the sharded Welch PSD (include/spectral.h: sp_welch_export): this shard's additive state,
+    float64[5*nfft + 8] (torch tensor on the device for device input).  Sum the states of all shards, then welch_apply."""
+    w = _win32(win)
+    n = 5 * w.size + 8
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = _torch_samples(x)
+        nm = xs.numel() if nmean is None else int(nmean)
+        out = torch.empty(n, dtype=torch.float64, device=xs.device)
+        check(lib().sp_welch_export(ptr(xs.data_ptr()), _tcode(xs), xs.numel(), ptr(w), w.size, int(hop), int(nframes), nm,
+                                    ptr(out.data_ptr()), 1))
+        return out
+    xs = _ffi.as_samples(x)
+    nm = xs.size if nmean is None else int(nmean)
+    out = np.empty(n, dtype=np.float64)
+    _ffi.init()
+    check(lib().sp_welch_export(ptr(xs), _ffi.dtype_code(xs.dtype), xs.size, ptr(w), w.size, int(hop), int(nframes), nm,
+                                ptr(out), 0))
+    return out
+
+
+def welch_apply(state, win, frames_total, sided=SIDED_TWO, scale=1.0):
+    """PSD of the whole stream (global-mean detrend) from the summed shard states: float64[nbins]."""
+    w = _win32(win)
+    nb = nbins(w.size, sided)
+    if _is_torch(state):
+        st = state.to(torch.float64).contiguous()
+        out = torch.empty(nb, dtype=torch.float64, device=st.device)
+        check(lib().sp_welch_apply(ptr(st.data_ptr()), ptr(w), w.size, int(frames_total), sided, float(scale),
+                                   ptr(out.data_ptr()), 1))
+        return out
+    st = np.ascontiguousarray(state, dtype=np.float64)
+    out = np.empty(nb, dtype=np.float64)
+    _ffi.init()
+    check(lib().sp_welch_apply(ptr(st), ptr(w), w.size, int(frames_total), sided, float(scale), ptr(out), 0))
+    return out
+
+
 def welch_finish(nfft, mean, frames_total, sided=SIDED_TWO, scale=1.0, like=None):
     """Second half: apply the (global) mean -- (2,) float64 [re, im], same kind of array welch_accum returned, or None
     for the shard's own mean -- and return scale/frames_total * sum_{local frames} |X|^2 as float64 [nbins]."""

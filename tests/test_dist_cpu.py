@@ -1,6 +1,5 @@
 """N > 1 path on CPU: two gloo ranks run pyfft_amd.dist.welch_psd_sharded with the CPU oracle standing in for the
-device kernels (the HIP library cannot run here); checks the shard plan (halo, ownership), the order/size of the two
-collectives, and that the sharded result equals the single-process PSD of the whole stream."""
+device kernels (the HIP library cannot run here); checks the shard plan (halo, ownership), the single collective, and that the sharded result equals the single-process PSD of the whole stream."""
 import os
 import sys
 
@@ -37,19 +36,33 @@ def test_shard_plan_partitions_frames_and_samples():
 
 
 def _oracle_backend(win, nfft):
-    """(accum, finish) with the semantics of sp_welch_accum / sp_welch_finish, computed by the oracle."""
-    state = {}
+    """(export, apply) with the semantics of sp_welch_export / sp_welch_apply, computed in float64 by the oracle's
+    building blocks: spectra against a deliberately rough local mean estimate mu0 (the mean of the shard's first 100
+    samples), the additive state, and the formula that applies the global mean to the summed state."""
+    W = np.fft.fft(np.asarray(win, dtype=np.float64))
 
-    def accum(x, w, hop, frames, nmean):
-        state.update(x=np.asarray(x), hop=hop, frames=frames)
-        s = np.asarray(x[:nmean]).astype(np.complex128).sum()
-        return np.array([s.real, s.imag])
+    def export(x, w, hop, frames, nmean):
+        x = np.asarray(x).astype(np.complex128)
+        mu0 = x[:100].mean()
+        idx = (np.arange(frames) * hop)[:, None] + np.arange(nfft)[None, :]
+        X = np.fft.fft(np.asarray(w, dtype=np.float64) * (x[idx] - mu0), axis=-1)
+        A, B = (np.abs(X) ** 2).sum(axis=0), X.sum(axis=0)
+        C = np.conj(mu0) * B
+        s = x[:nmean].sum()
+        sc = [frames * mu0.real, frames * mu0.imag, frames * abs(mu0) ** 2, s.real, s.imag, float(frames), float(nmean), 0.0]
+        return np.concatenate([A, np.stack([B.real, B.imag], axis=1).ravel(), np.stack([C.real, C.imag], axis=1).ravel(), sc])
 
-    def finish(n, mean, frames_total, sided, scale, like):
-        x = state["x"].astype(np.complex128) - (mean[0] + 1j * mean[1])
-        p = O.welch_psd_stream(x, win, n, state["hop"], state["frames"], 1.0, detrend_style=0) * np.sum(win ** 2)
-        return p * state["frames"] / frames_total * scale
-    return accum, finish
+    def apply(st, w, frames_total, sided, scale):
+        n = nfft
+        A, B, C, sc = st[:n], st[n:3 * n].reshape(n, 2), st[3 * n:5 * n].reshape(n, 2), st[5 * n:]
+        B, C = B[:, 0] + 1j * B[:, 1], C[:, 0] + 1j * C[:, 1]
+        mu = (sc[3] + 1j * sc[4]) / sc[6]
+        S1 = sc[0] + 1j * sc[1]
+        P = A - 2 * np.real(np.conj(W) * (np.conj(mu) * B - C)) + np.abs(W) ** 2 * (abs(mu) ** 2 * sc[5]
+                                                                                   - 2 * np.real(np.conj(mu) * S1) + sc[2])
+        assert sided == 2
+        return np.fft.fftshift(P) * scale / frames_total
+    return export, apply
 
 
 def _worker(rank, world, port, total, nfft, hop, out_dir):

@@ -266,6 +266,42 @@ def test_welch_accum_finish_sharded(E):
     np.testing.assert_allclose(pa + pb, ref, rtol=2e-4, atol=1e-6 * ref.max())
 
 
+@pytest.mark.parametrize("sided", ["two", "one", "raw"])
+def test_welch_export_apply_sharded(E, sided):
+    """one-collective form: the states of three unequal shards (different means, a mean 30x the signal) add up, and
+    sp_welch_apply turns the sum into the single-pass PSD of the whole stream; numpy and device inputs"""
+    import torch
+    sd = {"two": E.SIDED_TWO, "one": E.SIDED_ONE, "raw": E.SIDED_RAW}[sided]
+    rng = np.random.default_rng(123)
+    nfft, hop = 2048, 512
+    nsig = nfft + hop * 301
+    x = (rng.standard_normal(nsig) + 1j * rng.standard_normal(nsig) + (30.0 - 11.0j)).astype(np.complex64)
+    x[: nsig // 3] += 2.0
+    x[-nsig // 5:] -= 1.0j
+    M = (nsig - nfft) // hop + 1
+    win = O.windows("Hanning", nwins=nfft)
+    ref = E.welch_psd(x, win, hop, M, detrend=True, sided=sd, scale=3.0)
+    cuts = [0, M // 4, M // 4 + M // 3, M]
+    states = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        xs = x[a * hop: (b - 1) * hop + nfft] if b < M else x[a * hop:]
+        own = (b - a) * hop if b < M else nsig - a * hop
+        if a == cuts[1]:
+            st = E.welch_export(torch.from_numpy(xs).cuda(), win, hop, b - a, nmean=own).cpu().numpy()
+        else:
+            st = E.welch_export(xs, win, hop, b - a, nmean=own)
+        assert st.shape == (5 * nfft + 8,)
+        states.append(st)
+    tot = np.sum(states, axis=0)
+    assert tot[5 * nfft + 5] == M and tot[5 * nfft + 6] == nsig
+    p = E.welch_apply(tot, win, M, sided=sd, scale=3.0)
+    np.testing.assert_allclose(p, ref, rtol=2e-4, atol=2e-6 * ref.max())
+    # against the oracle too (two-sided)
+    if sided == "two":
+        oref = O.welch_psd_stream(x, win, nfft, hop, M, 1.0) * np.sum(win ** 2) * 3.0
+        np.testing.assert_allclose(p, oref, rtol=2e-4, atol=2e-6 * oref.max())
+
+
 def test_dist_world1_on_device(E):
     """pyfft_amd.dist with device tensors and no process group (world = 1) == welch_psd"""
     import torch
