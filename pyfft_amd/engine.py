@@ -206,6 +206,7 @@ def welch_apply(state, win, frames_total, sided=SIDED_TWO, scale=1.0):
     w = _win32(win)
     nb = nbins(w.size, sided)
     if _is_torch(state):
+        _bind_stream(state)
         st = state.to(torch.float64).contiguous()
         out = torch.empty(nb, dtype=torch.float64, device=st.device)
         check(lib().sp_welch_apply(ptr(st.data_ptr()), ptr(w), w.size, int(frames_total), sided, float(scale),
