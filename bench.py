@@ -35,7 +35,7 @@ from pyfft_amd.dist import shard_plan, welch_psd_sharded   # noqa: E402
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 # HBM bytes per launch of the dominant kernel from rocprofv3 PMC (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, KiB
 # units), profiles/r01_pmc_welch_carry.txt; measured at the default workload only -- null for any other size
-TRAFFIC_BYTES_PER_LAUNCH = {(28, 4096): 1.08248e6 * 1024 * 2 + 65536 * 1024}
+TRAFFIC_BYTES_PER_LAUNCH = {(28, 4096): 1.06561e6 * 1024 * 2 + 32768 * 1024}
 
 
 def synth_stream(n0, n, device, seed):

@@ -28,13 +28,15 @@ struct RunPart {
     int64_t groups, fpg;
     int blocks;
 };
-// groups_per_cu: 8 by default = four rounds at the 2 resident workgroups per CU of the 200-VGPR segment kernels
-// (measured at the metric shape: 8 -> 0.674, 12 -> 0.690 ms).  SP_GROUPS_PER_CU overrides it (experiments).
+// groups_per_cu: 4 by default = two rounds at the 2 resident workgroups per CU of the 200-VGPR segment kernels.  Measured
+// on the metric shape (bench.py step / kernel, ms): 2 -> 0.651 / 0.607, 4 -> 0.660 / 0.605, 8 -> 0.680 / 0.634,
+// 3 -> 0.73 / 0.685 (one and a half rounds), 6 ~ 8, 12 and 24 worse: longer runs amortise the per-workgroup prologue
+// (twiddle constants, first frame) and halve the partial spectra the epilogue has to sum.  SP_GROUPS_PER_CU overrides it.
 inline int default_groups_per_cu() {
     static const int v = [] {
         const char *e = getenv("SP_GROUPS_PER_CU");
         const int k = e ? atoi(e) : 0;
-        return k > 0 ? k : 8;
+        return k > 0 ? k : 4;
     }();
     return v;
 }
