@@ -69,11 +69,15 @@ int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int directio
  *      detrend (global detrend over x[0:nsig], fft_analysis.py:2148, :2539-2549):
  *        SP_DETREND_CONST  (0) subtract the given constant mean_re + i mean_im (0,0 = no detrend),
  *        SP_DETREND_MEAN   (1) the library computes and subtracts the mean (one extra pass over x),
- *        SP_DETREND_LINEAR (2) the library fits and subtracts the least-squares line.
+ *        SP_DETREND_LINEAR (2) the library fits and subtracts the least-squares line,
+ *        SP_DETREND_SEGMEAN (3) every segment's own mean is removed before the window (the per-segment detrend of the
+ *                              matplotlib.mlab estimators behind fft_analysis.psd/csd/coh, :1060-1155); sp_welch_psd and
+ *                              sp_welch_csd only.
  *      nbins = Nnyquist for SP_SIDED_ONE (nfft/2, or (nfft+1)/2 when odd), nfft otherwise. */
 #define SP_DETREND_CONST 0
 #define SP_DETREND_MEAN 1
 #define SP_DETREND_LINEAR 2
+#define SP_DETREND_SEGMEAN 3
 int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop,
                  int64_t nframes, int detrend, double mean_re, double mean_im, int sided,
                  double scale, double *pxx_out, int mem);

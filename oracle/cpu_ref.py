@@ -599,3 +599,96 @@ def csd_matrix(x, win, nfft, hop, nframes, Fs, detrend_style=1):
         X = np.fft.rfft(win[None, :] * x[:, g * hop:g * hop + nfft], axis=-1)     # [nch, nb]
         G += X.T[:, :, None] * np.conj(X.T[:, None, :])
     return G / (nframes * Fs * S2)
+
+
+# ---------------------------------------------------------------------------------------------
+# matplotlib.mlab wrappers  psd / csd / coh / coh2  (fft_analysis.py:1060-1155).  The algorithm lives in matplotlib
+# (mlab._spectral_helper, pinned here by version 3.10.8 of the build image): restated below from its published
+# behaviour and pinned by tests/golden/mlab_wrappers.npz, which the reference itself produced (make_golden_mlab.py).
+# Segments of NFFT samples, step NFFT - noverlap, count (len - noverlap) // step; detrend PER SEGMENT; symmetric Hann
+# (mlab.window_hanning = np.hanning(NFFT) * x); conj(X) Y; / Fs / sum(w^2); one-sided doubling of every bin except DC
+# (and Nyquist when NFFT is even); mean over segments; freqs = fftfreq with a positive Nyquist.
+# ---------------------------------------------------------------------------------------------
+def mlab_segments(n, nfft, noverlap):
+    step = nfft - noverlap
+    return (n - noverlap) // step, step
+
+
+def _mlab_detrend(seg, kind):
+    if kind in (None, "none"):
+        return seg
+    if kind == "mean":
+        return seg - seg.mean(axis=-1, keepdims=True)
+    if kind == "linear":
+        k = np.arange(seg.shape[-1], dtype=np.float64)
+        kc = k - k.mean()
+        slope = (seg * kc).sum(axis=-1, keepdims=True) / (kc * kc).sum()
+        return seg - seg.mean(axis=-1, keepdims=True) - slope * kc
+    raise ValueError(kind)
+
+
+def mlab_csd(x, y, nfft, fs, detrend="none", noverlap=0):
+    """(Pxy, freqs) of matplotlib.mlab.csd(x, y, NFFT=nfft, Fs=fs, detrend=detrend, window=window_hanning,
+    noverlap=noverlap) for real x, y (one-sided, scale_by_freq).  mlab.psd(x) = mlab_csd(x, x).real."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64)
+    nseg, step = mlab_segments(x.size, nfft, noverlap)
+    idx = (np.arange(nseg) * step)[:, None] + np.arange(nfft)[None, :]
+    w = np.hanning(nfft)
+    nb = nfft // 2 + 1
+    X = np.fft.fft(w * _mlab_detrend(x[idx], detrend), axis=-1)[:, :nb]
+    Y = np.fft.fft(w * _mlab_detrend(y[idx], detrend), axis=-1)[:, :nb]
+    res = np.conj(X) * Y / fs / np.sum(w ** 2)
+    if nfft % 2 == 0:
+        res[:, 1:-1] *= 2.0
+    else:
+        res[:, 1:] *= 2.0
+    f = np.fft.fftfreq(nfft, 1.0 / fs)[:nb].copy()
+    if nfft % 2 == 0:
+        f[-1] *= -1.0
+    return res.mean(axis=0), f
+
+
+def _band(P, F, fmin, fmax, peak_threshold=None):
+    keep = np.ones(P.shape, dtype=bool)
+    if fmin is not None:
+        keep &= F >= fmin
+    if fmax is not None:
+        keep &= F <= fmax
+    if peak_threshold is not None:
+        keep &= P > peak_threshold
+    return P[keep], F[keep]
+
+
+def mlab_psd_wrapper(x, fs, nfft=2048, fmin=None, fmax=None, detrend="none", peak_threshold=None, ov=0.67):
+    """fft_analysis.psd (:1113-1131)"""
+    P, F = mlab_csd(x, x, nfft, fs, detrend, int(np.floor(ov * nfft)))
+    return _band(P.real, F, fmin, fmax, peak_threshold)
+
+
+def mlab_csd_wrapper(x, y, fs, nfft=2048, fmin=0, fmax=500e3, detrend="none", peak_threshold=None, ov=0.67):
+    """fft_analysis.csd (:1134-1155)"""
+    P, F = mlab_csd(x, y, nfft, fs, detrend, int(np.floor(ov * nfft)))
+    return _band(P, F, fmin, fmax, peak_threshold)
+
+
+def mlab_coh_wrapper(x, y, fs, nfft=2048, fmin=0.0, fmax=500e3, detrend="mean", ov=0.67):
+    """fft_analysis.coh (:1060-1088): sqrt of the magnitude-squared coherence"""
+    nov = int(ov * nfft)
+    Pxx, F = mlab_csd(x, x, nfft, fs, detrend, nov)
+    Pyy, _ = mlab_csd(y, y, nfft, fs, detrend, nov)
+    Pxy, _ = mlab_csd(x, y, nfft, fs, detrend, nov)
+    c2 = np.abs(Pxy) ** 2 / (Pxx.real * Pyy.real)
+    keep = (F <= fmax) & (F >= fmin)
+    return np.sqrt(c2[keep]), F[keep]
+
+
+def mlab_coh2_wrapper(x, y, fs, nfft=4096, fmin=0, fmax=500e3):
+    """fft_analysis.coh2 (:1090-1110).  PARITY UNPINNED: the reference passes noverlap = nfft/2 as a float, which the
+    matplotlib of this image rejects (TypeError), so the reference cannot produce a fixture; restated with nfft // 2."""
+    fxx, f = mlab_csd(x, x, nfft, fs, "none", nfft // 2)
+    fyy, _ = mlab_csd(y, y, nfft, fs, "none", nfft // 2)
+    fxy, _ = mlab_csd(x, y, nfft, fs, "none", nfft // 2)
+    keep = np.abs(f) <= fmax
+    return {"coh": (np.abs(fxy * np.conj(fxy)) / (fxx * fyy)).real[keep], "f": f[keep], "PS": np.abs(fxx)[keep],
+            "pha": np.arctan2(fxy.imag, fxy.real)[keep]}

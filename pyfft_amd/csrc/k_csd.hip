@@ -4,10 +4,10 @@ namespace sp {
 
 int launch_csd(LaunchCtx c, const void *x, const void *y, bool cplx, int nch, int64_t y_ld, const float *win, int hop,
                int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,
-               const RunPart &rp) {
+               const RunPart &rp, int segmean) {
 #define L_(XT, CP, LN)                                                                                \
     hipLaunchKernelGGL((k_welch_csd<XT, CP, LN>), dim3(rp.blocks, nch), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, \
-                       y, y_ld, win, hop, nframes, rp.fpg, trend_x, trend_y, xf.tb, partial, rp.groups)
+                       y, y_ld, win, hop, nframes, rp.fpg, trend_x, trend_y, xf.tb, partial, rp.groups, segmean)
 #define M_(XT)                                                                                        \
     if (cplx) {                                                                                       \
         if (lin) L_(XT, true, true);                                                                  \

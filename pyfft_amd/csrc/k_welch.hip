@@ -43,8 +43,9 @@ static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int
 
 int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
                  bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, cf *spartial,
-                 const char **kname) {
+                 const char **kname, int segmean) {
     if (kname) *kname = "k_welch";
+    if (segmean) allow_carry = false;        // per-segment detrend exists only in the generic kernel
     if (allow_carry && welch_carry_eligible(xf, hop, lin)) {
         bool done = false;
 #define TRY_(NN)                                                                                      \
@@ -66,14 +67,14 @@ int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int ho
 #define M_(XT)                                                                                        \
     if (cplx) {                                                                                       \
         if (lin) hipLaunchKernelGGL((k_welch<XT, true, true>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), \
-                                    c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, partial);   \
+                                    c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, partial, segmean);   \
         else hipLaunchKernelGGL((k_welch<XT, true, false>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), \
-                                c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, partial);       \
+                                c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, partial, segmean);       \
     } else {                                                                                          \
         if (lin) hipLaunchKernelGGL((k_welch<XT, false, true>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), \
-                                    c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, partial);   \
+                                    c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, partial, segmean);   \
         else hipLaunchKernelGGL((k_welch<XT, false, false>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), \
-                                c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, partial);       \
+                                c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, partial, segmean);       \
     }
     SP_DISPATCH_X(xf, M_)
 #undef M_

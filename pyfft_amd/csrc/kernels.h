@@ -127,6 +127,37 @@ template <bool LIN> __device__ __forceinline__ cf detrended(cf a, const Trend &t
     X xf;                                                                                             \
     xf.init(tb, tid);
 
+// mean of one frame spread over the T threads of a group (v[t] <-> sample tid + T t, slots >= n excluded): the
+// per-segment detrend of the matplotlib.mlab estimators (fft_analysis.py:1060-1155 psd / csd / coh).  Reduction through
+// the group's exchange image; every thread of the workgroup must call it (barriers).
+template <class C> __device__ __forceinline__ cf group_mean(const cf (&v)[C::R], cf *lds, int tid, int n, bool exact) {
+    cf s = mk(0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        const float keep = (exact || tid + C::T * t < n) ? 1.f : 0.f;
+        s = s + keep * v[t];
+    }
+    if constexpr (C::T == 1) {
+        return (1.f / (float)n) * s;
+    } else {
+        __syncthreads();                      // the image may still be read by the previous transform
+        lds[tid] = s;
+        __syncthreads();
+        constexpr int W = C::T < 16 ? C::T : 16;
+        cf p = mk(0.f, 0.f);
+        if (tid < W) {
+            for (int j = tid; j < C::T; j += W) p = p + lds[j];
+        }
+        __syncthreads();
+        if (tid < W) lds[tid] = p;
+        __syncthreads();
+        cf tot = mk(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < W; ++j) tot = tot + lds[j];
+        return (1.f / (float)n) * tot;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // A7  batched C2C FFT (fft_analysis.py:2096-2116).  inverse through conj(fft(conj(.)))/n.
 // BigTw (optional): after the transform, element (row b, column i) is multiplied by W_Ntot^{b*i} -- the twiddle
@@ -224,7 +255,7 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restri
 template <class X, bool CPLX, bool LIN>
 __global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, const float *__restrict__ win, int hop,
                                                      int64_t nframes, int64_t fpg, const float *__restrict__ trend,
-                                                     XfTables tb, float *__restrict__ partial) {
+                                                     XfTables tb, float *__restrict__ partial, int segmean) {
     SP_KERNEL_PROLOGUE(X)
     float w[C::R], acc[C::R];
 #pragma unroll
@@ -247,6 +278,11 @@ __global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, 
         for (int t = 0; t < C::R; ++t) {
             const int j = tid + C::T * t;
             v[t] = load_sample(x, base + (X::EXACT || j < n ? j : n - 1), CPLX);
+        }
+        if (segmean) {                              // per-segment mean (mlab detrend='mean'); workgroup-uniform
+            const cf m = group_mean<C>(v, lds, tid, n, X::EXACT);
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) v[t] = v[t] - m;
         }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = w[t] * detrended<LIN>(v[t], tr, base + tid + C::T * t);
@@ -811,7 +847,7 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_csd(const void *__restrict__
                                                          int64_t y_ld, const float *__restrict__ win, int hop,
                                                          int64_t nframes, int64_t fpg, const float *__restrict__ trend_x,
                                                          const float *__restrict__ trend_y, XfTables tb,
-                                                         float *__restrict__ partial, int64_t groups_total) {
+                                                         float *__restrict__ partial, int64_t groups_total, int segmean) {
     SP_KERNEL_PROLOGUE(X)
     const int ch = blockIdx.y;
     float w[C::R], axx[C::R], ayy[C::R];
@@ -838,6 +874,15 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_csd(const void *__restrict__
             const int64_t idx = base + (X::EXACT || j < n ? j : n - 1);
             vx[t] = load_sample(x, idx, CPLX);
             vy[t] = load_sample(y, yoff + idx, CPLX);
+        }
+        if (segmean) {
+            const cf mx = group_mean<C>(vx, lds, tid, n, X::EXACT);
+            const cf my = group_mean<C>(vy, lds, tid, n, X::EXACT);
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                vx[t] = vx[t] - mx;
+                vy[t] = vy[t] - my;
+            }
         }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {

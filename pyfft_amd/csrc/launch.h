@@ -100,7 +100,7 @@ int launch_xc_out(LaunchCtx c, const cf *r, int64_t n, int64_t L, const double *
 bool welch_carry_eligible(const Xf &xf, int hop, bool lin);
 int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
                  bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, cf *spartial,
-                 const char **kname);
+                 const char **kname, int segmean = 0);
 int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, double *part, float *trend);
 int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *partial, const cf *spartial,
                      int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st, double *sum_out);
@@ -117,7 +117,7 @@ int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64
                    int nchan = 1, int64_t x_cs = 0, int64_t out_cs = 0);
 int launch_csd(LaunchCtx c, const void *x, const void *y, bool cplx, int nch, int64_t y_ld, const float *win, int hop,
                int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,
-               const RunPart &rp);
+               const RunPart &rp, int segmean = 0);
 int launch_csd_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
                       double *pxx, double *pyy, double *pxy);
 int launch_stft(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,

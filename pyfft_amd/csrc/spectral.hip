@@ -742,7 +742,12 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
     if (ensure_init()) return -1;
     if (check_frames("sp_welch_psd", nsig, nfft, hop, nframes)) return -1;
     if (sided < 1 || sided > 3) return fail("sp_welch_psd: bad sided");
-    if (detrend < 0 || detrend > 2) return fail("sp_welch_psd: detrend must be 0, 1 or 2");
+    if (detrend < 0 || detrend > 3) return fail("sp_welch_psd: detrend must be 0..3");
+    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : 0;      // per-segment mean: generic kernel, no global trend
+    if (segmean) {
+        detrend = SP_DETREND_CONST;
+        mean_re = mean_im = 0.0;
+    }
     std::lock_guard<std::mutex> lk(g.mu);
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
@@ -772,7 +777,7 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         TrendBuf tb;
         if (get_trendbuf(1, &tb)) return -1;
         if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
-        const bool pair = !cplx && nframes >= 2 && !env_flag("SP_NO_REALPAIR");
+        const bool pair = !cplx && nframes >= 2 && !segmean && !env_flag("SP_NO_REALPAIR");
         const RunPart rp = run_partition(xf.L, pair ? (nframes + 1) / 2 : nframes, g.ncu);
         if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
         float *partial = (float *)g.work.p;
@@ -785,7 +790,7 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
                 g.last_kernel = "k_welch_rp";
             } else {
                 LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, partial,
-                                       rp, allow_carry, nullptr, &g.last_kernel));
+                                       rp, allow_carry, nullptr, &g.last_kernel, segmean));
             }
         }
         LAUNCHCHK(launch_welch_finish(lc(), partial, rp.groups, xf, sided, scale / (double)nframes, out_d, pair ? 1 : 0));
@@ -914,7 +919,12 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     if (check_frames("sp_welch_csd", nsig, nfft, hop, nframes)) return -1;
     if (nch < 1 || y_ld < nsig) return fail("sp_welch_csd: bad nch / y_ld");
     if (sided < 1 || sided > 3) return fail("sp_welch_csd: bad sided");
-    if (detrend < 0 || detrend > 2) return fail("sp_welch_csd: detrend must be 0, 1 or 2");
+    if (detrend < 0 || detrend > 3) return fail("sp_welch_csd: detrend must be 0..3");
+    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : 0;
+    if (segmean) {
+        detrend = SP_DETREND_CONST;
+        mean_x = mean_y = nullptr;
+    }
     std::lock_guard<std::mutex> lk(g.mu);
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
@@ -956,7 +966,8 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     const RunPart rp = run_partition_2d(xf.L, nframes, g.ncu, nch);
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L * 4 * (size_t)nch)) return -1;
     float *partial = (float *)g.work.p;
-    if (!cplx && csd_rp_eligible(xf) && nch >= 2 && nframes >= 2 && !env_flag("SP_NO_REALPAIR") && !env_flag("SP_CSD_XIY")) {
+    if (!cplx && !segmean && csd_rp_eligible(xf) && nch >= 2 && nframes >= 2 && !env_flag("SP_NO_REALPAIR") &&
+        !env_flag("SP_CSD_XIY")) {
         // real x against many real channels: the reference's packed pair spectra once, then one transform per
         // (channel, frame PAIR); Pxx from the real-pair PSD kernel.  (SP_CSD_XIY=1: the x + i y_c form below.)
         const int64_t npairs = (nframes + 1) / 2;
@@ -975,7 +986,7 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         float *px = (float *)g.bigT.p;
         LAUNCHCHK(launch_welch_rp(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, px, rpx));
         LAUNCHCHK(launch_welch_finish(lc(), px, rpx.groups, xf, sided, scale / (double)nframes, pxx_d, 1));
-    } else if (!cplx && csd_rp_eligible(xf) && !env_flag("SP_NO_REALPAIR")) {
+    } else if (!cplx && !segmean && csd_rp_eligible(xf) && !env_flag("SP_NO_REALPAIR")) {
         // real x, y: x + i y_c in one transform per (frame, channel)
         LAUNCHCHK(launch_csd_rp(lc(), (const float *)xd, (const float *)yd, nch, y_ld, (const float *)win_d, hop, nframes,
                                 tb.f, tb.f + 4, detrend == 2, xf, partial, rp));
@@ -983,7 +994,7 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
                                        pxy_d));
     } else {
         LAUNCHCHK(launch_csd(lc(), xd, yd, cplx, nch, y_ld, (const float *)win_d, hop, nframes, tb.f, tb.f + 4,
-                             detrend == 2, xf, partial, rp));
+                             detrend == 2, xf, partial, rp, segmean));
         LAUNCHCHK(launch_csd_finish(lc(), partial, rp.groups, xf, nch, sided, scale / (double)nframes, pxx_d, pyy_d,
                                     pxy_d));
     }

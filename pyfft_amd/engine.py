@@ -55,12 +55,15 @@ def nbins(nfft, sided):
 
 
 def _detrend_args(detrend, mean_value):
-    """detrend: False/0/None none, True/1/'mean' mean, 2/'linear' least-squares line; an explicit mean_value
+    """detrend: False/0/None none, True/1/'mean' mean, 2/'linear' least-squares line, 3/'segmean' every segment's own
+    mean (welch_psd / welch_csd only: the matplotlib.mlab convention); an explicit mean_value
     (with detrend truthy) is subtracted as a constant instead of being computed."""
     if detrend in (None, False, 0, "none"):
         return _ffi.DETREND_CONST, 0j
     if detrend in (2, "linear"):
         return _ffi.DETREND_LINEAR, 0j
+    if detrend in (3, "segmean"):
+        return _ffi.DETREND_SEGMEAN, 0j
     if mean_value is not None:
         return _ffi.DETREND_CONST, complex(mean_value)
     return _ffi.DETREND_MEAN, 0j

@@ -290,6 +290,90 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
 # ------------------------------------------------------------------------------------------
 # fftanal
 # ------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------------------------
+# psd / csd / coh / coh2 (fft_analysis.py:1060-1155): the reference's thin wrappers over matplotlib.mlab.psd / csd.
+# mlab's estimator (symmetric Hann = mlab.window_hanning, step NFFT - noverlap, detrend PER SEGMENT, conj(X) Y / Fs /
+# sum(w^2), one-sided doubling except DC and Nyquist, mean over segments) runs on the device through welch_psd /
+# welch_csd; only the band selection stays on the host.  Real input (the reference's use); detrend 'none' or 'mean'.
+# ------------------------------------------------------------------------------------------------------------------
+def _mlab_detrend_code(detrend):
+    if detrend in (None, "none", False):
+        return False
+    if detrend == "mean":
+        return "segmean"
+    raise NotImplementedError("mlab detrend=%r on the device (have 'none' and 'mean')" % (detrend,))
+
+
+def _mlab_onesided(nfft, fs):
+    nb = nfft // 2 + 1
+    f = np.fft.fftfreq(nfft, 1.0 / fs)[:nb].copy()
+    dbl = np.full(nb, 2.0)
+    dbl[0] = 1.0
+    if nfft % 2 == 0:
+        f[-1] *= -1.0
+        dbl[-1] = 1.0
+    return f, dbl, nb
+
+
+def _mlab_spectra(x, y, fs, nfft, noverlap, detrend):
+    """(Pxx, Pyy, Pxy, F) as matplotlib.mlab.psd / csd return them (y None: Pxx only)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    step = nfft - int(noverlap)
+    nseg = (x.size - int(noverlap)) // step
+    if nseg < 1:
+        raise ValueError("signal shorter than one segment")
+    w = np.hanning(nfft)
+    f, dbl, nb = _mlab_onesided(nfft, fs)
+    scale = 1.0 / (fs * np.sum(w ** 2))
+    d = _mlab_detrend_code(detrend)
+    if y is None:
+        pxx = _E.welch_psd(x, w, step, nseg, detrend=d, sided=_E.SIDED_RAW, scale=scale)
+        return np.asarray(pxx)[:nb] * dbl, None, None, f
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    pxx, pyy, pxy = _E.welch_csd(x, y[None, :], w, step, nseg, detrend=d, sided=_E.SIDED_RAW, scale=scale)
+    return (np.asarray(pxx)[:nb] * dbl, np.asarray(pyy)[0, :nb] * dbl, np.asarray(pxy)[0, :nb] * dbl, f)
+
+
+def _band(P, F, fmin, fmax, peak_threshold):
+    keep = np.ones(P.shape, dtype=bool)
+    if fmin is not None:
+        keep &= F >= fmin
+    if fmax is not None:
+        keep &= F <= fmax
+    if peak_threshold is not None:
+        keep &= P > peak_threshold
+    return P[keep], F[keep]
+
+
+def psd(x, fs, nfft=2048, fmin=None, fmax=None, detrend='none', peak_threshold=None, ov=0.67):
+    """Power spectral density within a frequency range (fft_analysis.py:1113-1131): (pso, fo)."""
+    P, _, _, F = _mlab_spectra(x, None, fs, nfft, int(np.floor(ov * nfft)), detrend)
+    return _band(P, F, fmin, fmax, peak_threshold)
+
+
+def csd(x, y, fs, nfft=2048, fmin=0, fmax=500e3, detrend='none', peak_threshold=None, ov=0.67):
+    """Cross power spectral density conj(X) Y within a frequency range (fft_analysis.py:1134-1155): (pso, fo)."""
+    _, _, P, F = _mlab_spectra(x, y, fs, nfft, int(np.floor(ov * nfft)), detrend)
+    return _band(P, F, fmin, fmax, peak_threshold)
+
+
+def coh(x, y, fs, nfft=2048, fmin=0.0, fmax=500e3, detrend='mean', ov=0.67):
+    """Coherence (square root of the magnitude-squared coherence) below a maximum frequency (fft_analysis.py:1060-1088)."""
+    Pxx, Pyy, Pxy, F = _mlab_spectra(x, y, fs, nfft, int(ov * nfft), detrend)
+    c2 = np.abs(Pxy) ** 2 / (Pxx * Pyy)
+    keep = (F <= fmax) & (F >= fmin)
+    return np.sqrt(c2[keep]), F[keep]
+
+
+def coh2(x, y, fs, nfft=4096, fmin=0, fmax=500e3, detrend='none', peak_treshold=None):
+    """Magnitude-squared coherence, cross-phase and auto-power w.r.t. x (fft_analysis.py:1090-1110).  The reference passes
+    noverlap = nfft/2 as a float, which current matplotlib rejects; nfft // 2 is used (parity unpinned, DESIGN.md)."""
+    Pxx, Pyy, Pxy, F = _mlab_spectra(x, y, fs, nfft, nfft // 2, 'none')
+    keep = np.abs(F) <= fmax
+    return {'coh': (np.abs(Pxy) ** 2 / (Pxx * Pyy))[keep], 'f': F[keep], 'PS': np.abs(Pxx)[keep],
+            'pha': np.arctan2(Pxy.imag, Pxy.real)[keep]}
+
+
 class fftanal(Struct):
     """Welch / STFT analysis object (reference: fft_analysis.py:1695-2048).
 

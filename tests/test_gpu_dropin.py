@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
+from oracle import cpu_ref as O
 
 pytestmark = pytest.mark.gpu
 
@@ -207,3 +208,32 @@ def test_fftfilt_and_notch(P):
     w = np.hanning(11)
     pad = np.r_[s[10:0:-1], s, s[-2:-12:-1]]
     close_rel(smooth(s, 11, "hanning"), np.convolve(w / w.sum(), pad, mode="valid"), 1e-5, "smooth")
+
+
+def test_mlab_wrappers_psd_csd_coh():
+    """psd / csd / coh / coh2 (the reference's matplotlib.mlab wrappers) against the fixture the reference produced;
+    per-segment mean detrend, symmetric Hann, arbitrary hop, even and non-power-of-two nfft"""
+    import pyfft_amd as P
+    g = load_golden("mlab_wrappers")
+    x, y, fs = g["x"], g["y"], float(g["fs"])
+    p, f = P.psd(x, fs)
+    np.testing.assert_allclose(f, g["psd_f"], rtol=1e-12)
+    np.testing.assert_allclose(p, g["psd_p"], rtol=3e-4, atol=1e-6 * g["psd_p"].max())
+    p, f = P.psd(x, fs, nfft=500, fmin=20.0, fmax=300.0, detrend="mean", ov=0.5)
+    np.testing.assert_allclose(f, g["psd2_f"], rtol=1e-12)
+    np.testing.assert_allclose(p, g["psd2_p"], rtol=3e-4, atol=1e-6 * g["psd2_p"].max())
+    p, f = P.csd(x, y, fs)
+    np.testing.assert_allclose(f, g["csd_f"], rtol=1e-12)
+    assert np.max(np.abs(p - g["csd_p"])) <= 3e-4 * np.abs(g["csd_p"]).max()
+    p, f = P.csd(x, y, fs, nfft=1024, fmin=None, fmax=None, detrend="mean", ov=0.75)
+    assert np.max(np.abs(p - g["csd2_p"])) <= 3e-4 * np.abs(g["csd2_p"]).max()
+    c, f = P.coh(x, y, fs)
+    np.testing.assert_allclose(f, g["coh_f"], rtol=1e-12)
+    np.testing.assert_allclose(c, g["coh_c"], rtol=2e-3, atol=2e-4)
+    c, f = P.coh(x, y, fs, nfft=512, fmin=10.0, fmax=400.0, detrend="none", ov=0.5)
+    np.testing.assert_allclose(c, g["coh2_c"], rtol=2e-3, atol=2e-4)
+    r = P.coh2(x, y, fs)
+    ref = O.mlab_coh2_wrapper(x, y, fs)                      # parity unpinned: the reference's coh2 raises (float noverlap)
+    np.testing.assert_allclose(r["f"], ref["f"], rtol=1e-12)
+    np.testing.assert_allclose(r["coh"], ref["coh"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(r["PS"], ref["PS"], rtol=3e-4, atol=1e-6 * ref["PS"].max())
