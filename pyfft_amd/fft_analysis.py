@@ -614,6 +614,82 @@ class fftanal(Struct):
                 setattr(self, "L" + p[1:], tmp)
                 setattr(self, "varL" + p[1:], (tmp ** 2) * (getattr(self, "var" + p) / np.abs(getattr(self, p)) ** 2))
 
+    # ---- geometry / normalisation getters under the reference's names (fft_analysis.py:2054-2076, :2412-2510)
+    @staticmethod
+    def _getNwins(nsig, Navr, windowoverlap):
+        return _nwins(nsig, Navr, windowoverlap)
+
+    @staticmethod
+    def _getNoverlap(nwins, windowoverlap):
+        return _noverlap(nwins, windowoverlap)
+
+    @staticmethod
+    def _getNavr(nsig, nwins, noverlap):
+        return _navr(nsig, nwins, noverlap)
+
+    @staticmethod
+    def _getNnyquist(nfft):
+        return _nnyquist(nfft)
+
+    @staticmethod
+    def _getNorms(win, Nnyquist, Fs):
+        return _norms(win, Nnyquist, Fs)
+
+    @staticmethod
+    def _getMINoverlap(nsig, nwins, Navr):
+        noverlap = 1
+        while fftanal._checkCOLA(nsig, nwins, noverlap) is False and noverlap < 1e4:
+            noverlap += 1
+        return noverlap
+
+    @staticmethod
+    def _getMAXoverlap(nsig, nwins, Navr):
+        noverlap = int(nwins) - 1
+        while fftanal._checkCOLA(nsig, nwins, noverlap) is False and noverlap > 0:
+            noverlap -= 1
+        return noverlap
+
+    def getNavr(self):
+        self.Navr = fftanal._getNavr(self.nsig, self.nwins, self.noverlap)
+        return self.Navr
+
+    def getNwins(self):
+        self.nwins = fftanal._getNwins(self.nsig, self.Navr, self.overlap)
+        return self.nwins
+
+    def getNoverlap(self):
+        self.noverlap = fftanal._getNoverlap(self.nwins, self.overlap)
+        return self.noverlap
+
+    def getNnyquist(self):
+        self.Nnyquist = self._getNnyquist(self.nwins)
+        return self.Nnyquist
+
+    def getNorms(self):
+        self.S1, self.S2, self.NENBW, self.ENBW = fftanal._getNorms(self.win, self.Nnyquist, self.Fs)
+
+    def crosscorr_stft(self):
+        """Per-segment correlations from the per-segment spectra (fft_analysis.py:1880-1920); inverse FFTs on the GPU."""
+        nfft = self.nwins
+        for p in ("Pxx_seg", "Pyy_seg", "Pxy_seg"):
+            if hasattr(self, p):
+                tmp = np.array(getattr(self, p), dtype=np.complex128)
+                if self.onesided:
+                    tmp[..., 1:-1] *= 0.5
+                    if nfft % 2:
+                        tmp[..., -1] *= 0.5
+                    tmp = np.sqrt(nfft) * _ifft_cols(tmp.T, nfft, True).T
+                else:
+                    tmp = np.sqrt(nfft) * _ifft_cols(np.fft.ifftshift(tmp, axes=-1).T, nfft, False).T
+                if p.startswith("Pxx"):
+                    self.Ex_seg = tmp[..., 0].copy()
+                if p.startswith("Pyy"):
+                    self.Ey_seg = tmp[..., 0].copy()
+                setattr(self, "R" + p[1:], np.fft.fftshift(tmp, axes=-1))
+        if hasattr(self, "Rxy_seg"):
+            self.corrcoef_seg = self.Rxy_seg.copy() / np.sqrt(self.Ex_seg * self.Ey_seg)[..., None]
+        self.lags = (np.asarray(range(1, nfft + 1), dtype=int) - self.Nnyquist) / self.Fs
+
     def crosscorr(self):
         """Correlations from the averaged spectra (fft_analysis.py:1840-1878); inverse FFTs on the GPU."""
         nfft = self.nwins

@@ -237,3 +237,35 @@ def test_mlab_wrappers_psd_csd_coh():
     np.testing.assert_allclose(r["f"], ref["f"], rtol=1e-12)
     np.testing.assert_allclose(r["coh"], ref["coh"], rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(r["PS"], ref["PS"], rtol=3e-4, atol=1e-6 * ref["PS"].max())
+
+
+def test_fftanal_crosscorr_stft_and_getters():
+    """crosscorr_stft (fft_analysis.py:1880-1920) restated with numpy's irfft/ifft, and the reference-named getters"""
+    import pyfft_amd as P
+    rng = np.random.default_rng(4)
+    n, fs = 6000, 1.0e3
+    t = np.arange(n) / fs
+    x = np.sin(2 * np.pi * 50 * t) + 0.3 * rng.standard_normal(n)
+    y = np.sin(2 * np.pi * 50 * t + 0.7) + 0.3 * rng.standard_normal(n)
+    for onesided in (True, False):
+        ft = P.fftanal(t, x, y, tbounds=[t[0], t[-1]], Navr=8, windowoverlap=0.5, windowfunction="hanning",
+                       onesided=onesided, plotit=False, verbose=False, segments=True)
+        ft.pwelch()
+        ft.crosscorr_stft()
+        nfft = ft.nwins
+        for name in ("Pxx_seg", "Pxy_seg"):
+            tmp = np.array(getattr(ft, name), dtype=np.complex128)
+            if onesided:
+                tmp[..., 1:-1] *= 0.5
+                if nfft % 2:
+                    tmp[..., -1] *= 0.5
+                ref = np.sqrt(nfft) * np.fft.irfft(tmp, n=nfft, axis=-1)
+            else:
+                ref = np.sqrt(nfft) * np.fft.ifft(np.fft.ifftshift(tmp, axes=-1), n=nfft, axis=-1)
+            ref = np.fft.fftshift(ref, axes=-1)
+            got = getattr(ft, "R" + name[1:])
+            assert got.shape == ref.shape
+            assert np.max(np.abs(got - ref)) <= 5e-6 * np.abs(ref).max()
+        assert ft.corrcoef_seg.shape == ft.Rxy_seg.shape and ft.lags.shape == (nfft,)
+        assert ft.getNnyquist() == P.fftanal._getNnyquist(nfft)
+        assert ft.getNoverlap() == P.fftanal._getNoverlap(nfft, 0.5) and ft.getNavr() == P.fftanal._getNavr(ft.nsig, nfft, ft.noverlap)
