@@ -524,6 +524,38 @@ class fftanal(Struct):
         dt = (tvec[-1] - tvec[0]) / (len(tvec) - 1)
         return tt, freq, Xseg.astype(np.complex128), pseg * dt / self.S2
 
+    @staticmethod
+    def _fft_win(sig, **kwargs):
+        """Static multi-channel twin of fft_win (fft_analysis.py:2554-2640): sig [nt] or [nt, nch]; returns
+        (tt, freq, Xfft [nch, Navr, nbins] squeezed, pseg [nch, Navr] squeezed)."""
+        if kwargs.get('detrendwin', False):
+            raise NotImplementedError("per-window detrend (detrendwin=True)")
+        x = np.asarray(sig)
+        tvec = kwargs.get('tvec', None)
+        onesided = kwargs.get('onesided', False)
+        win, nwins, Navr, noverlap = kwargs['win'], kwargs['nwins'], kwargs['Navr'], kwargs['noverlap']
+        Nnyquist, S1, S2, ENBW = kwargs['Nnyquist'], kwargs['S1'], kwargs['S2'], kwargs['ENBW']
+        dflag = _check_detrend(kwargs['detrend_style'])
+        if tvec is None:
+            tvec = np.linspace(0.0, 1.0, x.shape[0])
+        Fs = kwargs.get('Fs', _fs(tvec))
+        hop = nwins - noverlap
+        cols = x[:, None] if x.ndim == 1 else x
+        amp = 1.0 / (S1 * np.sqrt(ENBW))
+        Xs, ps = [], []
+        for c in range(cols.shape[1]):
+            Xc, pc = _E.stft_frames(np.ascontiguousarray(cols[:, c]), win, hop, Navr, detrend=dflag, sided=_sided(onesided),
+                                    amp_scale=amp, want_pseg=True)
+            Xs.append(np.asarray(Xc).astype(np.complex128))
+            ps.append(np.asarray(pc))
+        csum = np.concatenate(([0.0], np.cumsum(np.asarray(tvec, dtype=np.float64))))
+        st = np.arange(Navr) * hop
+        tt = (csum[st + nwins] - csum[st]) / nwins
+        freq = np.fft.fftfreq(nwins, 1.0 / Fs)
+        freq = freq[:Nnyquist] if onesided else np.fft.fftshift(freq)
+        dt = (tvec[-1] - tvec[0]) / (len(tvec) - 1)
+        return tt, freq, np.stack(Xs).squeeze(), (np.stack(ps) * dt / S2).squeeze()
+
     # -- Welch (fft_analysis.py:1831-1836, :1924-2018)
     def Xstft(self):
         sig = self.__trimsig__(self.sigx, self.ibounds)

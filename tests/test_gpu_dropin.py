@@ -269,3 +269,27 @@ def test_fftanal_crosscorr_stft_and_getters():
         assert ft.corrcoef_seg.shape == ft.Rxy_seg.shape and ft.lags.shape == (nfft,)
         assert ft.getNnyquist() == P.fftanal._getNnyquist(nfft)
         assert ft.getNoverlap() == P.fftanal._getNoverlap(nfft, 0.5) and ft.getNavr() == P.fftanal._getNavr(ft.nsig, nfft, ft.noverlap)
+
+
+def test_fftanal_static_fft_win_matches_instance():
+    """fftanal._fft_win (the static multi-channel twin, fft_analysis.py:2554-2640) == fft_win per channel"""
+    import pyfft_amd as P
+    rng = np.random.default_rng(5)
+    n, fs = 5000, 2.0e3
+    t = np.arange(n) / fs
+    x = np.sin(2 * np.pi * 70 * t) + 0.2 * rng.standard_normal(n) + 0.5
+    y = np.cos(2 * np.pi * 70 * t) + 0.2 * rng.standard_normal(n) - 0.1
+    ft = P.fftanal(t, x, y, tbounds=[t[0], t[-1]], Navr=6, windowoverlap=0.5, windowfunction="hanning", onesided=True,
+                   plotit=False, verbose=False)
+    i0, i1 = ft.ibounds
+    tt, freq, X1, p1 = ft.fft_win(x[i0:i1], t[i0:i1])
+    _, _, Y1, q1 = ft.fft_win(y[i0:i1], t[i0:i1])
+    kw = dict(tvec=t[i0:i1], onesided=True, win=ft.win, nwins=ft.nwins, Navr=ft.Navr, noverlap=ft.noverlap,
+              Nnyquist=ft.Nnyquist, detrend_style=ft.detrendstyle, S1=ft.S1, S2=ft.S2, ENBW=ft.ENBW, Fs=ft.Fs)
+    tt2, freq2, X2, p2 = P.fftanal._fft_win(np.stack([x[i0:i1], y[i0:i1]], axis=1), **kw)
+    assert X2.shape == (2,) + X1.shape and p2.shape == (2,) + p1.shape
+    np.testing.assert_allclose(tt2, tt)
+    np.testing.assert_allclose(freq2, freq)
+    np.testing.assert_allclose(X2[0], X1, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(X2[1], Y1, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(p2[1], q1, rtol=1e-6)
