@@ -3,10 +3,11 @@
 namespace sp {
 
 int launch_stft(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
-                bool lin, const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg) {
+                bool lin, const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg,
+                int segmean) {
 #define L_(XT, CP, LN)                                                                                \
     hipLaunchKernelGGL((k_stft<XT, CP, LN>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, win, hop, \
-                       nframes, rp.fpg, trend, xf.tb, sided, amp, out_power, out, pseg)
+                       nframes, rp.fpg, trend, xf.tb, sided, amp, out_power, out, pseg, segmean)
 #define M_(XT)                                                                                        \
     if (cplx) {                                                                                       \
         if (lin) L_(XT, true, true);                                                                  \

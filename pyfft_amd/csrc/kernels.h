@@ -1239,7 +1239,7 @@ template <class X, bool CPLX, bool LIN>
 __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, const float *__restrict__ win, int hop,
                                                     int64_t nframes, int64_t fpg, const float *__restrict__ trend,
                                                     XfTables tb, int sided, float amp, int out_power,
-                                                    void *__restrict__ out, double *__restrict__ pseg) {
+                                                    void *__restrict__ out, double *__restrict__ pseg, int segmean) {
     SP_KERNEL_PROLOGUE(X)
     float w[C::R];
 #pragma unroll
@@ -1261,6 +1261,11 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
         for (int t = 0; t < C::R; ++t) {
             const int j = tid + C::T * t;
             v[t] = load_sample(x, base + (X::EXACT || j < n ? j : n - 1), CPLX);
+        }
+        if (segmean) {                              // per-window mean (fft_win detrendwin=True, mean style); uniform
+            const cf m = group_mean<C>(v, lds, tid, n, X::EXACT);
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) v[t] = v[t] - m;
         }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {

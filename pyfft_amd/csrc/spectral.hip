@@ -1160,7 +1160,12 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
     if (ensure_init()) return -1;
     if (check_frames("sp_stft", nsig, nfft, hop, nframes)) return -1;
     if (sided < 1 || sided > 3) return fail("sp_stft: bad sided");
-    if (detrend < 0 || detrend > 2) return fail("sp_stft: detrend must be 0, 1 or 2");
+    if (detrend < 0 || detrend > 3) return fail("sp_stft: detrend must be 0..3");
+    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : 0;       // per-window mean: generic kernel, no global trend
+    if (segmean) {
+        detrend = SP_DETREND_CONST;
+        mean_re = mean_im = 0.0;
+    }
     std::lock_guard<std::mutex> lk(g.mu);
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
@@ -1193,7 +1198,7 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
         fm = g.work.p;
     }
     if (pseg_d) HIPCHK(hipMemsetAsync(pseg_d, 0, sizeof(double) * (size_t)nframes, g.stream));
-    const bool pair = !cplx && !xf.blue && xf.L >= 32 && nframes >= 2 && !env_flag("SP_NO_REALPAIR");
+    const bool pair = !cplx && !segmean && !xf.blue && xf.L >= 32 && nframes >= 2 && !env_flag("SP_NO_REALPAIR");
     if (pair) {
         const RunPart rp = run_partition(xf.L, (nframes + 1) / 2, g.ncu);
         LAUNCHCHK(launch_stft_rp(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, sided,
@@ -1201,7 +1206,7 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
     } else {
         const RunPart rp = run_partition(xf.L, nframes, g.ncu);
         LAUNCHCHK(launch_stft(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, sided,
-                              (float)amp_scale, out_kind, fm, pseg_d));
+                              (float)amp_scale, out_kind, fm, pseg_d, segmean));
     }
     if (out_major == 1) LAUNCHCHK(launch_transpose(lc(), fm, fin, nframes, (int64_t)nb, (int)osz));
     if (!mem) {

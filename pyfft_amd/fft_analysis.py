@@ -502,14 +502,18 @@ class fftanal(Struct):
 
     # -- fft_win (fft_analysis.py:2126-2203)
     def fft_win(self, sig, tvec=None, detrendwin=False):
-        if detrendwin:
-            raise NotImplementedError("per-window detrend (detrendwin=True)")
         sig = np.asarray(sig)
         if tvec is None:
             tvec = np.linspace(0.0, 1.0, len(sig))
         Fs = _fs(tvec)
         nwins, Navr, hop = self.nwins, self.Navr, self.nwins - self.noverlap
         dflag = _check_detrend(self.detrendstyle)
+        if detrendwin:
+            # per-window detrend instead of the global one (:2148 / :2171): the mean style runs in the kernel
+            if dflag is True or dflag == 1 or dflag == "mean":
+                dflag = "segmean"
+            elif dflag not in (None, False, 0, "none"):
+                raise NotImplementedError("per-window LINEAR detrend (detrendwin=True with detrend_style < 0)")
         amp = 1.0 / (self.S1 * np.sqrt(self.ENBW))                     # :2197, :2202
         Xseg, pseg = _E.stft_frames(sig, self.win, hop, Navr, detrend=dflag, sided=_sided(self.onesided),
                                     amp_scale=amp, want_pseg=True)

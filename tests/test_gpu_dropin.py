@@ -293,3 +293,34 @@ def test_fftanal_static_fft_win_matches_instance():
     np.testing.assert_allclose(X2[0], X1, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(X2[1], Y1, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(p2[1], q1, rtol=1e-6)
+
+
+def test_fft_win_detrendwin_mean():
+    """fft_win(detrendwin=True) (fft_analysis.py:2171): every window's own mean removed instead of the global mean"""
+    import pyfft_amd as P
+    rng = np.random.default_rng(6)
+    n, fs = 7000, 1.0e3
+    t = np.arange(n) / fs
+    x = np.sin(2 * np.pi * 40 * t) + 0.2 * rng.standard_normal(n) + 2.0 + 3.0 * t      # strong drift
+    for onesided in (True, False):
+        ft = P.fftanal(t, x, tbounds=[t[0], t[-1]], Navr=9, windowoverlap=0.5, windowfunction="hanning", onesided=onesided,
+                       plotit=False, verbose=False)
+        i0, i1 = ft.ibounds
+        tt, freq, X, pseg = ft.fft_win(x[i0:i1], t[i0:i1], detrendwin=True)
+        xs = x[i0:i1]
+        hop = ft.nwins - ft.noverlap
+        ref = []
+        for g in range(ft.Navr):
+            seg = xs[g * hop: g * hop + ft.nwins]
+            F = np.fft.fft(ft.win * (seg - seg.mean()))
+            if onesided:
+                F = F[:ft.Nnyquist].copy()
+                F[1:-1] *= np.sqrt(2)
+                if ft.nwins % 2:
+                    F[-1] *= np.sqrt(2)
+            else:
+                F = np.fft.fftshift(F)
+            ref.append(F / ft.S1 / np.sqrt(ft.ENBW))
+        ref = np.array(ref)
+        assert X.shape == ref.shape
+        assert np.max(np.abs(X - ref)) <= 2e-5 * np.abs(ref).max()
