@@ -28,6 +28,37 @@ int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_
     return 0;
 }
 
+// three-pass long transform pieces (power-of-two lengths; ncols is a multiple of the columns per workgroup)
+int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
+                    int conj_in, const Xf &xf, BigTw bt) {
+    if (xf.blue) return -1;
+    const int fpw = fpw_of(xf.L);
+    if (ncols % fpw || nouter < 1) return -1;
+    const int64_t ncb = ncols / fpw, total = ncb * nouter;
+    const int64_t cap = (int64_t)c.ncu * 4;                    // several blocks per workgroup amortise its twiddle set-up
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
+#define M_(XT)                                                                                        \
+    hipLaunchKernelGGL((k_fft_cols<XT::L>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, ncb, nouter, es, \
+                       os, twmul, conj_in, xf.tb, bt);
+    SP_DISPATCH_P(xf, M_)
+#undef M_
+    return 0;
+}
+
+int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B, int conj_out, float scale, const Xf &xf) {
+    if (xf.blue) return -1;
+    const int fpw = fpw_of(xf.L);
+    if (A % fpw) return -1;
+    const int64_t total = A * B / fpw, cap = (int64_t)c.ncu * 4;
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
+#define M_(XT)                                                                                        \
+    hipLaunchKernelGGL((k_fft_rows_rev<XT::L>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
+                       conj_out, scale, xf.tb);
+    SP_DISPATCH_P(xf, M_)
+#undef M_
+    return 0;
+}
+
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out) {
     const int blocks = strided_blocks(xf.L, batch, c.ncu);
 #define M_(XT)                                                                                        \

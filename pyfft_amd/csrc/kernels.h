@@ -253,6 +253,76 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restri
 }
 
 // ------------------------------------------------------------------------------------------
+// Three-pass long transform, N = A B C (n = a BC + b C + c,  k = ka + A kb + A B kc), every pass reading and writing
+// whole 128-byte lines and no transposes (3 x 16 B/point against the five passes of the four-step form):
+//   1  for every column m = b C + c:   T[ka][m]      = W_N^{m ka}     sum_a x[a][m]     W_A^{a ka}      (k_fft_cols)
+//   2  for every ka and column c:      T[ka][kb][c]  = W_N^{A c kb}   sum_b T[ka][b][c] W_B^{b kb}      (k_fft_cols, in place)
+//   3  for every row (ka, kb):         X[ka + A kb + A B kc] = sum_c T[ka][kb][c] W_C^{c kc}            (k_fft_rows_rev)
+// k_fft_cols: a workgroup owns FPW ADJACENT columns and its lanes run over the columns (group = thread % FPW, the
+// flipped mapping), so that element i of the FPW columns is one contiguous segment (128 B at L = 256).
+// ------------------------------------------------------------------------------------------
+template <int L>
+__global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
+                                                            int64_t nouter, int64_t es, int64_t os, int64_t twmul, int conj_in,
+                                                            XfTables tb, BigTw bt) {
+    using X = XfPow2<L>;
+    using C = typename X::C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *smem = reinterpret_cast<cf *>(smem_raw);
+    const int grp = C::FPW == 1 ? 0 : (int)threadIdx.x % C::FPW;
+    const int tid = C::FPW == 1 ? (int)threadIdx.x : (int)threadIdx.x / C::FPW;
+    cf *lds = smem + grp * C::LDS_PER;
+    X xf;
+    xf.init(tb, tid);
+    const float si = conj_in ? -1.f : 1.f;
+    // a workgroup walks over (outer, column block) pairs with the grid as stride: the twiddle set-up is paid once per
+    // workgroup, and at any time neighbouring workgroups read neighbouring 128-byte segments of the same rows
+    const int64_t total = nouter * ncolblocks;
+    for (int64_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+        const int64_t col = (idx % ncolblocks) * C::FPW + grp;
+        const int64_t base = (idx / ncolblocks) * os + col;
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, si * v[t].y);
+        xf.fwd(v, lds, tid, L);
+        const int64_t mc = twmul * col;
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int64_t m = mc * (int64_t)(tid + C::T * t);
+            v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
+        }
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) out[base + (int64_t)(tid + C::T * t) * es] = v[t];
+    }
+}
+
+// pass 3: rows (ka, kb) of T[ka][kb][c]; the FPW rows of a workgroup are adjacent ka of one kb, so that for one kc the
+// workgroup's outputs X[ka + A kb + A B kc] are contiguous
+template <int L>
+__global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restrict__ in, cf *__restrict__ out, int64_t A, int64_t B,
+                                                                int conj_out, float scale, XfTables tb) {
+    using X = XfPow2<L>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
+    const float so = conj_out ? -1.f : 1.f;
+    const int64_t AB = A * B, nblocks = AB / C::FPW;              // FPW divides A
+    for (int64_t idx = blockIdx.x; idx < nblocks; idx += gridDim.x) {
+        const int64_t j = idx * C::FPW + grp;
+        const int64_t ka = j % A, kb = j / A;
+        const cf *row = in + (ka * B + kb) * (int64_t)L;
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = row[tid + C::T * t];
+        xf.fwd(v, lds, tid, L);
+        const int64_t off = kb * A + ka;
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) out[(int64_t)(tid + C::T * t) * AB + off] = mk(scale * v[t].x, so * scale * v[t].y);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // A3+A4  fused Welch PSD (fft_analysis.py:2156-2176 loop + :1946 |X|^2 + :1980 mean), generic form.
 // Each group owns frames [gid*fpg, (gid+1)*fpg); |X|^2 is accumulated in registers over the
 // run, one partial spectrum per group goes to HBM.  trend[4] (device) is removed before the window

@@ -392,6 +392,17 @@ int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse) {
     if (g.bigT.ensure(sizeof(cf) * (size_t)N)) return -1;
     cf *tmp = (cf *)g.bigT.p;
     const float sc = inverse ? (float)(1.0 / (double)N) : 1.f;
+    if (lg >= 20 && !env_flag("SP_BIGFFT_5PASS") && !env_flag("SP_BIGFFT_2PASS")) {
+        // three passes over whole lines, N = A B C (kernels.h: k_fft_cols / k_fft_rows_rev)
+        const int la_ = (lg + 2) / 3, lb_ = (lg - la_ + 1) / 2, lc_ = lg - la_ - lb_;
+        const int64_t A = (int64_t)1 << la_, B = (int64_t)1 << lb_, C = (int64_t)1 << lc_;
+        Xf xa, xb, xc;
+        if (get_xf(A, &xa) || get_xf(B, &xb) || get_xf(C, &xc)) return -1;
+        LAUNCHCHK(launch_fft_cols(lc(), in, tmp, B * C, 1, B * C, 0, 1, inverse, xa, bt));
+        LAUNCHCHK(launch_fft_cols(lc(), tmp, tmp, C, A, C, B * C, A, 0, xb, bt));
+        LAUNCHCHK(launch_fft_rows_rev(lc(), tmp, out, A, B, inverse, sc, xc));
+        return 0;
+    }
     if (env_flag("SP_BIGFFT_2PASS") && N1 >= 16 && N2 >= 16) {
         // experiment, off by default (measured 0.90-1.19 ms against 0.83 for a 2^24-point Hilbert: the column reads run at
         // 1.3 TB/s even with XCD-local adjacent columns).  Two strided passes, no explicit transposes (x viewed as

@@ -131,3 +131,20 @@ def test_long_fft_two_pass_option_matches(monkeypatch):
         monkeypatch.delenv("SP_BIGFFT_2PASS")
         assert np.max(np.abs(a - b)) <= 2e-6 * np.abs(a).max()
         assert np.max(np.abs(bi - x)) <= 3e-6 * np.abs(x).max() and np.max(np.abs(ai - x)) <= 3e-6 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("lg", [20, 21, 22])
+def test_long_fft_three_pass_matches_numpy(lg, monkeypatch):
+    """the three-pass long transform (N = A B C, default from 2^20 points) against numpy, forward and inverse, and
+    against the five-pass form"""
+    from pyfft_amd import engine as E
+    rng = np.random.default_rng(lg)
+    n = 1 << lg
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    ref = np.fft.fft(x.astype(np.complex128))
+    a = E.fft(x)
+    assert np.max(np.abs(a - ref)) <= 4e-6 * np.abs(ref).max()
+    assert np.max(np.abs(E.ifft(a) - x)) <= 4e-6 * np.abs(x).max()
+    monkeypatch.setenv("SP_BIGFFT_5PASS", "1")
+    b = E.fft(x)
+    assert np.max(np.abs(a - b)) <= 3e-6 * np.abs(ref).max()
