@@ -30,7 +30,7 @@ int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_
 
 // three-pass long transform pieces (power-of-two lengths; ncols is a multiple of the columns per workgroup)
 int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
-                    int conj_in, const Xf &xf, BigTw bt) {
+                    int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n) {
     if (xf.blue) return -1;
     const int fpw = fpw_of(xf.L);
     if (ncols % fpw || nouter < 1) return -1;
@@ -39,7 +39,7 @@ int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t n
     const unsigned grid = (unsigned)(total < cap ? total : cap);
 #define M_(XT)                                                                                        \
     hipLaunchKernelGGL((k_fft_cols<XT::L>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, ncb, nouter, es, \
-                       os, twmul, conj_in, xf.tb, bt);
+                       os, twmul, conj_in, xf.tb, bt, hmask_n);
     SP_DISPATCH_P(xf, M_)
 #undef M_
     return 0;

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restri
 template <int L>
 __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
                                                             int64_t nouter, int64_t es, int64_t os, int64_t twmul, int conj_in,
-                                                            XfTables tb, BigTw bt) {
+                                                            XfTables tb, BigTw bt, int64_t hmask_n) {
     using X = XfPow2<L>;
     using C = typename X::C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -284,6 +284,17 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_cols(const cf *__restrict_
         cf v[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
+        if (hmask_n > 0) {
+            // analytic-signal mask (hilbert.py:63-64) applied while loading the spectrum for the inverse transform
+            // (pass 1 only: base + i*es is the bin index): k = 0 and k = nyq x1, 1..nyq-1 x2, above x0
+            const int64_t nyq = (hmask_n & 1) ? (hmask_n + 1) / 2 : hmask_n / 2;
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t k = base + (int64_t)(tid + C::T * t) * es;
+                const float h = (k == 0 || k == nyq) ? 1.f : (k < nyq ? 2.f : 0.f);
+                v[t] = h * v[t];
+            }
+        }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, si * v[t].y);
         xf.fwd(v, lds, tid, L);

@@ -380,7 +380,12 @@ int get_bigtw(int64_t N, BigTw *bt) {
 
 // N = 2^k, 2^14 <= N <= 2^26:  x viewed as [N1][N2]; transpose, N2 row FFTs of N1 (+ twiddle W_N^{n2 k1}),
 // transpose, N1 row FFTs of N2, transpose back to natural order.  5 passes over the data (80 B / point).
-int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse) {
+// three-pass form available for N (then hmask may be fused into the first pass of an inverse transform)
+bool big_three_pass(int64_t N) {
+    return is_pow2(N) && N >= ((int64_t)1 << 20) && !env_flag("SP_BIGFFT_5PASS") && !env_flag("SP_BIGFFT_2PASS");
+}
+
+int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 0) {
     int lg = 0;
     while (((int64_t)1 << lg) < N) ++lg;
     if (((int64_t)1 << lg) != N || lg > SP_MAX_BIG_LOG2) return fail("internal: dev_fft_big_pow2(%lld)", (long long)N);
@@ -392,13 +397,14 @@ int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse) {
     if (g.bigT.ensure(sizeof(cf) * (size_t)N)) return -1;
     cf *tmp = (cf *)g.bigT.p;
     const float sc = inverse ? (float)(1.0 / (double)N) : 1.f;
-    if (lg >= 20 && !env_flag("SP_BIGFFT_5PASS") && !env_flag("SP_BIGFFT_2PASS")) {
+    if (hmask && !big_three_pass(N)) return fail("internal: fused Hilbert mask needs the three-pass transform");
+    if (big_three_pass(N)) {
         // three passes over whole lines, N = A B C (kernels.h: k_fft_cols / k_fft_rows_rev)
         const int la_ = (lg + 2) / 3, lb_ = (lg - la_ + 1) / 2, lc_ = lg - la_ - lb_;
         const int64_t A = (int64_t)1 << la_, B = (int64_t)1 << lb_, C = (int64_t)1 << lc_;
         Xf xa, xb, xc;
         if (get_xf(A, &xa) || get_xf(B, &xb) || get_xf(C, &xc)) return -1;
-        LAUNCHCHK(launch_fft_cols(lc(), in, tmp, B * C, 1, B * C, 0, 1, inverse, xa, bt));
+        LAUNCHCHK(launch_fft_cols(lc(), in, tmp, B * C, 1, B * C, 0, 1, inverse, xa, bt, hmask ? N : 0));
         LAUNCHCHK(launch_fft_cols(lc(), tmp, tmp, C, A, C, B * C, A, 0, xb, bt));
         LAUNCHCHK(launch_fft_rows_rev(lc(), tmp, out, A, B, inverse, sc, xc));
         return 0;
@@ -1255,8 +1261,13 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
         for (int64_t b = 0; b < batch; ++b) {
             LAUNCHCHK(launch_pack_real(lc(), xd + b * x_ld, nuse, nullptr, nfft, A));
             if (dev_fft_any(A, A, nfft, 1, 0)) return -1;
-            LAUNCHCHK(launch_hilbert_mask(lc(), A, nfft));
-            if (dev_fft_any(A, od + b * nfft, nfft, 1, 1)) return -1;
+            if (big_three_pass(nfft)) {
+                // the mask rides on the first pass of the inverse transform
+                if (dev_fft_big_pow2(A, od + b * nfft, nfft, 1, 1)) return -1;
+            } else {
+                LAUNCHCHK(launch_hilbert_mask(lc(), A, nfft));
+                if (dev_fft_any(A, od + b * nfft, nfft, 1, 1)) return -1;
+            }
         }
     }
     if (!mem) {

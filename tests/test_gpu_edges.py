@@ -148,3 +148,20 @@ def test_long_fft_three_pass_matches_numpy(lg, monkeypatch):
     monkeypatch.setenv("SP_BIGFFT_5PASS", "1")
     b = E.fft(x)
     assert np.max(np.abs(a - b)) <= 3e-6 * np.abs(ref).max()
+
+
+def test_long_hilbert_three_pass_fused_mask(monkeypatch):
+    """2^20- and 2^21-point analytic signals: three-pass transforms with the mask fused into the inverse's first pass,
+    against the oracle and against the five-pass form with the separate mask kernel"""
+    from pyfft_amd import engine as E
+    rng = np.random.default_rng(77)
+    for n in (1 << 20, 1 << 21):
+        u = rng.standard_normal((1, n))
+        z = E.hilbert_rows(u, n)
+        ref = O.hilbert(u)
+        assert np.max(np.abs(z - ref)) <= 1e-4 * np.abs(ref).max()
+        assert np.max(np.abs(z.real - u)) <= 1e-4 * np.abs(u).max()
+        monkeypatch.setenv("SP_BIGFFT_5PASS", "1")
+        z5 = E.hilbert_rows(u, n)
+        monkeypatch.delenv("SP_BIGFFT_5PASS")
+        assert np.max(np.abs(z - z5)) <= 2e-5 * np.abs(ref).max()
