@@ -678,6 +678,18 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
     SP_KERNEL_PROLOGUE(X)
     (void)n;
     const cf mu = mk(trend[0], trend[1]);
+    // this single workgroup is one chain of memory round trips: everything that does not depend on a computed value
+    // (window, raw sums, FFT(window)) is fetched up front, together with the twiddle tables of the prologue
+    double a_pre[C::R];
+    cf wf_pre[C::R];
+    float win_pre[C::R];
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        const int k = tid + C::T * t;
+        a_pre[t] = A[k];
+        wf_pre[t] = Wf[k];
+        win_pre[t] = win[k];
+    }
     double dr, di;
     double tot_r = 0.0, tot_i = 0.0;
     if (!EXPORT && mean_in) {
@@ -758,7 +770,7 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
             a -= s.x;
             b -= s.y;
         }
-        const double wn = (double)win[nidx];
+        const double wn = (double)win_pre[t];
         v[t] = (grp == 0) ? mk((float)(wn * a), (float)(wn * b)) : mk(0.f, 0.f);
     }
     xf.fwd(v, lds, tid, N);
@@ -769,7 +781,7 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
             for (int t = 0; t < C::R; ++t) {
                 const int k = tid + C::T * t;
                 const double br = (double)v[t].x, bi = (double)v[t].y;
-                out[k] = A[k];
+                out[k] = a_pre[t];
                 out[N + 2 * k] = br;
                 out[N + 2 * k + 1] = bi;
                 out[3 * N + 2 * k] = mr * br + mi * bi;          // conj(mu0) B
@@ -795,9 +807,9 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
             const int k = tid + C::T * t;
             const int slot = bin_slot(k, N, sided);
             if (slot < 0) continue;
-            const double wr = Wf[k].x, wi = Wf[k].y;
+            const double wr = wf_pre[t].x, wi = wf_pre[t].y;
             const double er = dr * wr - di * wi, ei = dr * wi + di * wr;       // d * Wf[k]
-            const double p = A[k] - 2.0 * (er * (double)v[t].x + ei * (double)v[t].y) + (double)M * (er * er + ei * ei);
+            const double p = a_pre[t] - 2.0 * (er * (double)v[t].x + ei * (double)v[t].y) + (double)M * (er * er + ei * ei);
             out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
         }
     }
