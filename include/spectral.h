@@ -72,12 +72,14 @@ int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int directio
  *        SP_DETREND_LINEAR (2) the library fits and subtracts the least-squares line,
  *        SP_DETREND_SEGMEAN (3) every segment's own mean is removed before the window (the per-segment detrend of the
  *                              matplotlib.mlab estimators behind fft_analysis.psd/csd/coh, :1060-1155); sp_welch_psd,
- *                              sp_welch_csd and sp_stft (fft_win's detrendwin=True, mean style).
+ *                              sp_welch_csd and sp_stft (fft_win's detrendwin=True),
+ *        SP_DETREND_SEGLINEAR (4) the same with every segment's own least-squares line.
  *      nbins = Nnyquist for SP_SIDED_ONE (nfft/2, or (nfft+1)/2 when odd), nfft otherwise. */
 #define SP_DETREND_CONST 0
 #define SP_DETREND_MEAN 1
 #define SP_DETREND_LINEAR 2
 #define SP_DETREND_SEGMEAN 3
+#define SP_DETREND_SEGLINEAR 4
 int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop,
                  int64_t nframes, int detrend, double mean_re, double mean_im, int sided,
                  double scale, double *pxx_out, int mem);

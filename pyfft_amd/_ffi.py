@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SP_LIB_PATH") or os.path.join(_HERE, "lib", "libspect
 
 DTYPE_F32, DTYPE_C64 = 0, 1
 SIDED_ONE, SIDED_TWO, SIDED_RAW, SIDED_HALF = 1, 2, 3, 4
-DETREND_CONST, DETREND_MEAN, DETREND_LINEAR, DETREND_SEGMEAN = 0, 1, 2, 3
+DETREND_CONST, DETREND_MEAN, DETREND_LINEAR, DETREND_SEGMEAN, DETREND_SEGLINEAR = 0, 1, 2, 3, 4
 
 _lib = None
 

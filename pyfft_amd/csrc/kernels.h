@@ -164,6 +164,26 @@ template <class C> __device__ __forceinline__ cf group_mean(const cf (&v)[C::R],
     }
 }
 
+// per-segment detrend of one frame in place: mode 1 removes its mean, mode 2 its least-squares line
+// (slope = sum (i - ibar) x_i / sum (i - ibar)^2, sum (i - ibar)^2 = n (n^2 - 1) / 12).  Workgroup-uniform calls only.
+template <class C> __device__ __forceinline__ void segment_detrend(cf (&v)[C::R], cf *lds, int tid, int n, bool exact, int mode) {
+    const cf m = group_mean<C>(v, lds, tid, n, exact);
+    if (mode == 2 && n > 1) {
+        const float ibar = 0.5f * (float)(n - 1);
+        cf u[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) u[t] = ((float)(tid + C::T * t) - ibar) * v[t];
+        const cf su = group_mean<C>(u, lds, tid, n, exact);                  // (1/n) sum (i - ibar) x_i
+        const float inv = 12.f / ((float)n * (float)n - 1.f);                 // n / sum (i - ibar)^2  (times 1/n above)
+        const cf sl = inv * su;
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = v[t] - m - ((float)(tid + C::T * t) - ibar) * sl;
+    } else {
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = v[t] - m;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // A7  batched C2C FFT (fft_analysis.py:2096-2116).  inverse through conj(fft(conj(.)))/n.
 // BigTw (optional): after the transform, element (row b, column i) is multiplied by W_Ntot^{b*i} -- the twiddle
@@ -366,11 +386,7 @@ __global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, 
             const int j = tid + C::T * t;
             v[t] = load_sample(x, base + (X::EXACT || j < n ? j : n - 1), CPLX);
         }
-        if (segmean) {                              // per-segment mean (mlab detrend='mean'); workgroup-uniform
-            const cf m = group_mean<C>(v, lds, tid, n, X::EXACT);
-#pragma unroll
-            for (int t = 0; t < C::R; ++t) v[t] = v[t] - m;
-        }
+        if (segmean) segment_detrend<C>(v, lds, tid, n, X::EXACT, segmean);   // per-segment (mlab) detrend; uniform
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = w[t] * detrended<LIN>(v[t], tr, base + tid + C::T * t);
         xf.fwd(v, lds, tid, n);
@@ -975,13 +991,8 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_csd(const void *__restrict__
             vy[t] = load_sample(y, yoff + idx, CPLX);
         }
         if (segmean) {
-            const cf mx = group_mean<C>(vx, lds, tid, n, X::EXACT);
-            const cf my = group_mean<C>(vy, lds, tid, n, X::EXACT);
-#pragma unroll
-            for (int t = 0; t < C::R; ++t) {
-                vx[t] = vx[t] - mx;
-                vy[t] = vy[t] - my;
-            }
+            segment_detrend<C>(vx, lds, tid, n, X::EXACT, segmean);
+            segment_detrend<C>(vy, lds, tid, n, X::EXACT, segmean);
         }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
@@ -1361,11 +1372,7 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
             const int j = tid + C::T * t;
             v[t] = load_sample(x, base + (X::EXACT || j < n ? j : n - 1), CPLX);
         }
-        if (segmean) {                              // per-window mean (fft_win detrendwin=True, mean style); uniform
-            const cf m = group_mean<C>(v, lds, tid, n, X::EXACT);
-#pragma unroll
-            for (int t = 0; t < C::R; ++t) v[t] = v[t] - m;
-        }
+        if (segmean) segment_detrend<C>(v, lds, tid, n, X::EXACT, segmean);   // per-window detrend (fft_win detrendwin=True)
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int j = tid + C::T * t;

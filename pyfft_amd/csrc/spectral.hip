@@ -759,8 +759,8 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
     if (ensure_init()) return -1;
     if (check_frames("sp_welch_psd", nsig, nfft, hop, nframes)) return -1;
     if (sided < 1 || sided > 3) return fail("sp_welch_psd: bad sided");
-    if (detrend < 0 || detrend > 3) return fail("sp_welch_psd: detrend must be 0..3");
-    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : 0;      // per-segment mean: generic kernel, no global trend
+    if (detrend < 0 || detrend > 4) return fail("sp_welch_psd: detrend must be 0..4");
+    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : (detrend == SP_DETREND_SEGLINEAR ? 2 : 0);   // per-segment: generic kernel
     if (segmean) {
         detrend = SP_DETREND_CONST;
         mean_re = mean_im = 0.0;
@@ -936,8 +936,8 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     if (check_frames("sp_welch_csd", nsig, nfft, hop, nframes)) return -1;
     if (nch < 1 || y_ld < nsig) return fail("sp_welch_csd: bad nch / y_ld");
     if (sided < 1 || sided > 3) return fail("sp_welch_csd: bad sided");
-    if (detrend < 0 || detrend > 3) return fail("sp_welch_csd: detrend must be 0..3");
-    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : 0;
+    if (detrend < 0 || detrend > 4) return fail("sp_welch_csd: detrend must be 0..4");
+    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : (detrend == SP_DETREND_SEGLINEAR ? 2 : 0);
     if (segmean) {
         detrend = SP_DETREND_CONST;
         mean_x = mean_y = nullptr;
@@ -1177,8 +1177,8 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
     if (ensure_init()) return -1;
     if (check_frames("sp_stft", nsig, nfft, hop, nframes)) return -1;
     if (sided < 1 || sided > 3) return fail("sp_stft: bad sided");
-    if (detrend < 0 || detrend > 3) return fail("sp_stft: detrend must be 0..3");
-    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : 0;       // per-window mean: generic kernel, no global trend
+    if (detrend < 0 || detrend > 4) return fail("sp_stft: detrend must be 0..4");
+    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : (detrend == SP_DETREND_SEGLINEAR ? 2 : 0);   // per-window: generic kernel
     if (segmean) {
         detrend = SP_DETREND_CONST;
         mean_re = mean_im = 0.0;

@@ -64,6 +64,8 @@ def _detrend_args(detrend, mean_value):
         return _ffi.DETREND_LINEAR, 0j
     if detrend in (3, "segmean"):
         return _ffi.DETREND_SEGMEAN, 0j
+    if detrend in (4, "seglinear"):
+        return _ffi.DETREND_SEGLINEAR, 0j
     if mean_value is not None:
         return _ffi.DETREND_CONST, complex(mean_value)
     return _ffi.DETREND_MEAN, 0j

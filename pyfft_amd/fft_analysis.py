@@ -294,14 +294,16 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
 # psd / csd / coh / coh2 (fft_analysis.py:1060-1155): the reference's thin wrappers over matplotlib.mlab.psd / csd.
 # mlab's estimator (symmetric Hann = mlab.window_hanning, step NFFT - noverlap, detrend PER SEGMENT, conj(X) Y / Fs /
 # sum(w^2), one-sided doubling except DC and Nyquist, mean over segments) runs on the device through welch_psd /
-# welch_csd; only the band selection stays on the host.  Real input (the reference's use); detrend 'none' or 'mean'.
+# welch_csd; only the band selection stays on the host.  Real input (the reference's use).
 # ------------------------------------------------------------------------------------------------------------------
 def _mlab_detrend_code(detrend):
     if detrend in (None, "none", False):
         return False
     if detrend == "mean":
         return "segmean"
-    raise NotImplementedError("mlab detrend=%r on the device (have 'none' and 'mean')" % (detrend,))
+    if detrend == "linear":
+        return "seglinear"
+    raise ValueError("detrend must be 'none', 'mean' or 'linear' (got %r)" % (detrend,))
 
 
 def _mlab_onesided(nfft, fs):
@@ -510,10 +512,10 @@ class fftanal(Struct):
         dflag = _check_detrend(self.detrendstyle)
         if detrendwin:
             # per-window detrend instead of the global one (:2148 / :2171): the mean style runs in the kernel
-            if dflag is True or dflag == 1 or dflag == "mean":
+            if dflag == 1:
                 dflag = "segmean"
-            elif dflag not in (None, False, 0, "none"):
-                raise NotImplementedError("per-window LINEAR detrend (detrendwin=True with detrend_style < 0)")
+            elif dflag == 2:
+                dflag = "seglinear"
         amp = 1.0 / (self.S1 * np.sqrt(self.ENBW))                     # :2197, :2202
         Xseg, pseg = _E.stft_frames(sig, self.win, hop, Navr, detrend=dflag, sided=_sided(self.onesided),
                                     amp_scale=amp, want_pseg=True)
@@ -532,14 +534,14 @@ class fftanal(Struct):
     def _fft_win(sig, **kwargs):
         """Static multi-channel twin of fft_win (fft_analysis.py:2554-2640): sig [nt] or [nt, nch]; returns
         (tt, freq, Xfft [nch, Navr, nbins] squeezed, pseg [nch, Navr] squeezed)."""
-        if kwargs.get('detrendwin', False):
-            raise NotImplementedError("per-window detrend (detrendwin=True)")
         x = np.asarray(sig)
         tvec = kwargs.get('tvec', None)
         onesided = kwargs.get('onesided', False)
         win, nwins, Navr, noverlap = kwargs['win'], kwargs['nwins'], kwargs['Navr'], kwargs['noverlap']
         Nnyquist, S1, S2, ENBW = kwargs['Nnyquist'], kwargs['S1'], kwargs['S2'], kwargs['ENBW']
         dflag = _check_detrend(kwargs['detrend_style'])
+        if kwargs.get('detrendwin', False):
+            dflag = {0: 0, 1: "segmean", 2: "seglinear"}[dflag]
         if tvec is None:
             tvec = np.linspace(0.0, 1.0, x.shape[0])
         Fs = kwargs.get('Fs', _fs(tvec))

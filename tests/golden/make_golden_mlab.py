@@ -35,6 +35,10 @@ def main():
     d["csd_p"], d["csd_f"] = p, f
     p, f = fa.csd(x, y, fs, nfft=1024, fmin=None, fmax=None, detrend="mean", ov=0.75)
     d["csd2_p"], d["csd2_f"] = p, f
+    p, f = fa.psd(x, fs, nfft=1024, detrend="linear", ov=0.5)
+    d["psd3_p"], d["psd3_f"] = p, f
+    p, f = fa.csd(x, y, fs, nfft=600, fmin=None, fmax=None, detrend="linear", ov=0.25)
+    d["csd3_p"], d["csd3_f"] = p, f
     c, f = fa.coh(x, y, fs)
     d["coh_c"], d["coh_f"] = c, f
     c, f = fa.coh(x, y, fs, nfft=512, fmin=10.0, fmax=400.0, detrend="none", ov=0.5)

@@ -227,6 +227,10 @@ def test_mlab_wrappers_psd_csd_coh():
     assert np.max(np.abs(p - g["csd_p"])) <= 3e-4 * np.abs(g["csd_p"]).max()
     p, f = P.csd(x, y, fs, nfft=1024, fmin=None, fmax=None, detrend="mean", ov=0.75)
     assert np.max(np.abs(p - g["csd2_p"])) <= 3e-4 * np.abs(g["csd2_p"]).max()
+    p, f = P.psd(x, fs, nfft=1024, detrend="linear", ov=0.5)
+    np.testing.assert_allclose(p, g["psd3_p"], rtol=3e-4, atol=1e-6 * g["psd3_p"].max())
+    p, f = P.csd(x, y, fs, nfft=600, fmin=None, fmax=None, detrend="linear", ov=0.25)
+    assert np.max(np.abs(p - g["csd3_p"])) <= 3e-4 * np.abs(g["csd3_p"]).max()
     c, f = P.coh(x, y, fs)
     np.testing.assert_allclose(f, g["coh_f"], rtol=1e-12)
     np.testing.assert_allclose(c, g["coh_c"], rtol=2e-3, atol=2e-4)
@@ -293,6 +297,29 @@ def test_fftanal_static_fft_win_matches_instance():
     np.testing.assert_allclose(X2[0], X1, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(X2[1], Y1, rtol=1e-6, atol=1e-9)
     np.testing.assert_allclose(p2[1], q1, rtol=1e-6)
+
+
+def test_fft_win_detrendwin_linear():
+    """fft_win(detrendwin=True) with the linear style (detrend_style < 0): every window's own least-squares line removed"""
+    import pyfft_amd as P
+    rng = np.random.default_rng(8)
+    n, fs = 6000, 1.0e3
+    t = np.arange(n) / fs
+    x = np.sin(2 * np.pi * 33 * t) + 0.2 * rng.standard_normal(n) + 1.0 + 5.0 * t ** 2
+    ft = P.fftanal(t, x, tbounds=[t[0], t[-1]], Navr=7, windowoverlap=0.5, windowfunction="hanning", onesided=False,
+                   detrend=-1, plotit=False, verbose=False)
+    i0, i1 = ft.ibounds
+    tt, freq, X, pseg = ft.fft_win(x[i0:i1], t[i0:i1], detrendwin=True)
+    xs = x[i0:i1]
+    hop = ft.nwins - ft.noverlap
+    k = np.arange(ft.nwins)
+    ref = []
+    for g in range(ft.Navr):
+        seg = xs[g * hop: g * hop + ft.nwins]
+        seg = seg - np.polyval(np.polyfit(k, seg, 1), k)
+        ref.append(np.fft.fftshift(np.fft.fft(ft.win * seg)) / ft.S1 / np.sqrt(ft.ENBW))
+    ref = np.array(ref)
+    assert np.max(np.abs(X - ref)) <= 5e-5 * np.abs(ref).max()
 
 
 def test_fft_win_detrendwin_mean():

@@ -254,6 +254,10 @@ def test_mlab_wrappers_against_reference_fixture():
     np.testing.assert_allclose(p, g["csd_p"], rtol=1e-9, atol=1e-12 * np.abs(g["csd_p"]).max())
     p, f = O.mlab_csd_wrapper(x, y, fs, nfft=1024, fmin=None, fmax=None, detrend="mean", ov=0.75)
     np.testing.assert_allclose(p, g["csd2_p"], rtol=1e-9, atol=1e-12 * np.abs(g["csd2_p"]).max())
+    p, f = O.mlab_psd_wrapper(x, fs, nfft=1024, detrend="linear", ov=0.5)
+    np.testing.assert_allclose(p, g["psd3_p"], rtol=1e-9)
+    p, f = O.mlab_csd_wrapper(x, y, fs, nfft=600, fmin=None, fmax=None, detrend="linear", ov=0.25)
+    np.testing.assert_allclose(p, g["csd3_p"], rtol=1e-8, atol=1e-12 * np.abs(g["csd3_p"]).max())
     c, f = O.mlab_coh_wrapper(x, y, fs)
     np.testing.assert_allclose(f, g["coh_f"], rtol=1e-13)
     np.testing.assert_allclose(c, g["coh_c"], rtol=1e-9)
