@@ -274,8 +274,9 @@ def cxy_cxy2(Pxx, Pyy, Pxy):                                     # :1662-1680
 
 
 def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, windowfunction=None,
-               detrend_style=None, onesided=None, tper=None, minFreq=None):
-    """Homebrew branch of fft_pwelch (useMLAB=False).  Returns (freq, Pxy, Pxx, Pyy, Cxy, phi_xy, info-dict)."""
+               detrend_style=None, onesided=None, tper=None, minFreq=None, useMLAB=False):
+    """fft_pwelch: the homebrew branch (useMLAB=False, :339-446) or the matplotlib.mlab.csd branch (useMLAB=True,
+    :254-330).  Returns (freq, Pxy, Pxx, Pyy, Cxy, phi_xy, info-dict)."""
     calcNavr = Navr is None
     if windowfunction is None:
         windowfunction = "Hanning"
@@ -322,6 +323,37 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
     Nny = get_nnyquist(nfft)
     win = windows(windowfunction, nwins=nwins)
     S1, S2, NENBW, ENBW = get_norms(win, Nny, Fs)
+
+    if useMLAB:
+        # :254-330 -- mlab.csd(x, y_c, nfft, Fs, detrend=<per segment>, window=win, noverlap, sides, scale_by_freq=True):
+        # conj(X) Y / Fs / sum(w^2), mlab's one-sided doubling (all but DC and the even-length Nyquist), mean over
+        # (len - noverlap) // step segments; the reference then keeps the first Nnyquist bins (:317-326)
+        x_in, y_in = np.asarray(sigx[i0:i1], dtype=np.float64), np.asarray(sigy[i0:i1, :], dtype=np.float64)
+        step = nwins - noverlap
+        nseg = (x_in.shape[0] - noverlap) // step
+        idx = (np.arange(nseg) * step)[:, None] + np.arange(nfft)[None, :]
+        kind = "none" if not detrend_style else ("mean" if detrend_style > 0 else "linear")
+        X = np.fft.fft(win * _mlab_detrend(x_in[idx], kind), axis=-1)
+        Y = np.stack([np.fft.fft(win * _mlab_detrend(y_in[:, c][idx], kind), axis=-1) for c in range(nch)])
+        sc = 1.0 / (Fs * np.sum(win ** 2))
+        Pxx = (np.conj(X) * X).mean(axis=0) * sc
+        Pyy = (np.conj(Y) * Y).mean(axis=1) * sc
+        Pxy = (np.conj(X)[None] * Y).mean(axis=1) * sc
+        freq = np.fft.fftfreq(nfft, 1.0 / Fs)
+        if onesided:
+            nb = nfft // 2 + 1
+            dbl = np.full(nb, 2.0)
+            dbl[0] = 1.0
+            if nfft % 2 == 0:
+                dbl[-1] = 1.0
+            Pxx, Pyy, Pxy = (Pxx[:nb] * dbl)[:Nny], (Pyy[:, :nb] * dbl)[:, :Nny], (Pxy[:, :nb] * dbl)[:, :Nny]
+            freq = freq[:Nny]
+        else:
+            Pxx, Pyy, Pxy = np.fft.fftshift(Pxx), np.fft.fftshift(Pyy, axes=-1), np.fft.fftshift(Pxy, axes=-1)
+            freq = np.fft.fftshift(freq)
+        info = dict(S1=S1, S2=S2, NENBW=NENBW, ENBW=ENBW, nwins=nwins, noverlap=noverlap, Navr=Navr, Fs=Fs, nch=nch,
+                    ibnds=[i0, i1], win=win, reflecting=reflecting, minFreq=2.0 * Fs / nwins)
+        return pwelch_epilogue(freq, Pxx, Pyy.real.T, Pxy.T, info, onesided)
 
     x_in = detrend(sigx[i0:i1], detrend_style)                   # :353-357
     y_in = detrend(sigy[i0:i1, :], detrend_style)

@@ -129,8 +129,6 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
         windowfunction = "Hanning"
     if windowoverlap is None:
         windowoverlap = windows(windowfunction, verbose=False)
-    if useMLAB:
-        raise NotImplementedError("useMLAB=True (matplotlib.mlab.csd) is a CPU-only branch of the reference")
     if verbose is None:
         verbose = False
     if detrend_style is None:
@@ -196,12 +194,36 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
     hop = nwins - noverlap
     scale = 1.0 / (info.S1 ** 2) / info.ENBW                          # :432-440
     sided = _sided(onesided)
-    pxx, pyy, pxy = _E.welch_csd(x_in, y_in, win, hop, Navr, detrend=dflag, sided=sided, scale=scale)
     freq = np.fft.fftfreq(nfft, 1.0 / Fs)
-    freq = freq[:Nnyquist] if onesided else np.fft.fftshift(freq)
-    Pxx = pxx.astype(np.complex128)                                   # reference dtype: complex128 with zero imag
-    Pyy = pyy.T.astype(np.complex128)                                 # [nfreq, nch]
-    Pxy = np.ascontiguousarray(pxy.T)
+    if useMLAB:
+        # the matplotlib.mlab.csd branch (:254-330) on the device: the same window array, detrend PER SEGMENT,
+        # (len - noverlap) // step segments, conj(X) Y / Fs / sum(w^2), mlab's one-sided doubling (every bin but DC
+        # and the even-length Nyquist), then the first Nnyquist bins (:317-326)
+        nseg = (len(x_in) - noverlap) // hop
+        seg_d = {0: False, 1: "segmean", 2: "seglinear"}[dflag]
+        sc = 1.0 / (Fs * np.sum(np.asarray(win, dtype=np.float64) ** 2))
+        pxx, pyy, pxy = _E.welch_csd(x_in, y_in, win, hop, nseg, detrend=seg_d, sided=_E.SIDED_RAW, scale=sc)
+        if onesided:
+            nb = nfft // 2 + 1
+            dbl = np.full(nb, 2.0)
+            dbl[0] = 1.0
+            if nfft % 2 == 0:
+                dbl[-1] = 1.0
+            cut = lambda P: (P[..., :nb] * dbl)[..., :Nnyquist]           # noqa: E731
+            freq = freq[:Nnyquist]
+        else:
+            cut = lambda P: np.fft.fftshift(P, axes=-1)                   # noqa: E731
+            freq = np.fft.fftshift(freq)
+        Pxx = cut(np.asarray(pxx)).astype(np.complex128)
+        Pyy = cut(np.asarray(pyy)).T.astype(np.float64)                # the reference allocates Pyy as float64 (:294)
+        Pxy = np.ascontiguousarray(cut(np.asarray(pxy)).T)
+        want_segments = False                                             # mlab returns no per-segment arrays
+    else:
+        pxx, pyy, pxy = _E.welch_csd(x_in, y_in, win, hop, Navr, detrend=dflag, sided=sided, scale=scale)
+        freq = freq[:Nnyquist] if onesided else np.fft.fftshift(freq)
+        Pxx = pxx.astype(np.complex128)                               # reference dtype: complex128 with zero imag
+        Pyy = pyy.T.astype(np.complex128)                             # [nfreq, nch]
+        Pxy = np.ascontiguousarray(pxy.T)
 
     if want_segments:
         amp = 1.0

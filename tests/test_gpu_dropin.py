@@ -351,3 +351,21 @@ def test_fft_win_detrendwin_mean():
         ref = np.array(ref)
         assert X.shape == ref.shape
         assert np.max(np.abs(X - ref)) <= 2e-5 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("tag,kw", [("pwelch_usemlab_onesided", dict(Navr=15, windowoverlap=0.5, windowfunction="Hamming")),
+                                    ("pwelch_usemlab_twosided_linear", dict(Navr=9, windowoverlap=0.5, windowfunction="Hanning",
+                                                                            onesided=False, detrend_style=-1))])
+def test_fft_pwelch_usemlab_on_device(tag, kw):
+    """fft_pwelch(useMLAB=True): the reference's matplotlib.mlab.csd branch, per-segment detrend, on the device"""
+    import pyfft_amd as P
+    g = load_golden(tag)
+    t, x, y = g["t"], g["x"], g["y"]
+    freq, Pxy, Pxx, Pyy, Cxy, phi, info = P.fft_pwelch(t, x, y, [t[0], t[-2]], useMLAB=True, plotit=False, verbose=False, **kw)
+    np.testing.assert_allclose(freq, g["freq"], rtol=1e-12, atol=1e-9)
+    assert Pxx.shape == g["Pxx"].shape and Pyy.shape == g["Pyy"].shape and Pxy.shape == g["Pxy"].shape
+    assert np.max(np.abs(Pxx - g["Pxx"])) <= 3e-4 * np.abs(g["Pxx"]).max()
+    assert np.max(np.abs(Pyy - g["Pyy"])) <= 3e-4 * np.abs(g["Pyy"]).max()
+    assert np.max(np.abs(Pxy - g["Pxy"])) <= 3e-4 * np.abs(g["Pxy"]).max()
+    np.testing.assert_allclose(Cxy, g["Cxy"], rtol=5e-3, atol=5e-4)
+    assert np.max(np.abs(info.Rxy - g["info_Rxy"])) <= 5e-4 * np.abs(g["info_Rxy"]).max()

@@ -264,3 +264,17 @@ def test_mlab_wrappers_against_reference_fixture():
     c, f = O.mlab_coh_wrapper(x, y, fs, nfft=512, fmin=10.0, fmax=400.0, detrend="none", ov=0.5)
     np.testing.assert_allclose(c, g["coh2_c"], rtol=1e-9)
     assert int(g["cohb_ok"]) == 0          # the reference's coh2 raises under this matplotlib: no fixture
+
+
+@pytest.mark.parametrize("tag,kw", [("pwelch_usemlab_onesided", dict(Navr=15, windowoverlap=0.5, windowfunction="Hamming")),
+                                    ("pwelch_usemlab_twosided_linear", dict(Navr=9, windowoverlap=0.5, windowfunction="Hanning",
+                                                                            onesided=False, detrend_style=-1))])
+def test_fft_pwelch_usemlab_branch(tag, kw):
+    """fft_pwelch(useMLAB=True) (fft_analysis.py:254-330) as the reference computed it through matplotlib.mlab.csd"""
+    g = load_golden(tag)
+    t, x, y = g["t"], g["x"], g["y"]
+    freq, Pxy, Pxx, Pyy, Cxy, phi, info = O.fft_pwelch(t, x, y, tbounds=[t[0], t[-2]], useMLAB=True, **kw)
+    np.testing.assert_allclose(freq, g["freq"], rtol=1e-13, atol=1e-9)
+    for a, name in ((Pxx, "Pxx"), (Pyy, "Pyy"), (Pxy, "Pxy"), (Cxy, "Cxy")):
+        assert np.max(np.abs(np.asarray(a) - g[name])) <= 1e-11 * np.abs(g[name]).max(), name
+    np.testing.assert_allclose(info["Rxy"], g["info_Rxy"], rtol=1e-8, atol=1e-11 * np.abs(g["info_Rxy"]).max())
