@@ -112,6 +112,4 @@ def test_no_cpu_fallback_without_gpu():
 def test_unsupported_branches_raise():
     t = np.arange(100.0)
     with pytest.raises(NotImplementedError):
-        pyfft_amd.fft_pwelch(t, np.zeros(100), np.zeros(100), useMLAB=True)
-    with pytest.raises(NotImplementedError):
         pyfft_amd.fft_pwelch(t, np.zeros(50), np.zeros(100))       # nT-model branch
