@@ -434,8 +434,6 @@ class fftanal(Struct):
         self.frange = kwargs.get("frange", None)
         self.axes = kwargs.get("axes", -1)
         self.segments = kwargs.get("segments", True)
-        if self.useMLAB:
-            raise NotImplementedError("useMLAB=True is a CPU-only branch of the reference")
         if self.tvecy is not None:
             raise NotImplementedError("tvecy resampling needs pybaseutils.utils.interp (absent from the reference)")
         if self.onesided is None:
@@ -654,6 +652,9 @@ class fftanal(Struct):
         self.averagewins()
 
     def stft(self):
+        if self.useMLAB:
+            # the reference switches to scipy.signal.stft here (:1806-1824: zero-padded boundaries, padded frames)
+            raise NotImplementedError("fftanal.stft with useMLAB=True (scipy.signal.stft branch); fftpwelch() supports useMLAB")
         self.pwelch()
 
     def fftpwelch(self):

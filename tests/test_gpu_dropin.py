@@ -369,3 +369,17 @@ def test_fft_pwelch_usemlab_on_device(tag, kw):
     assert np.max(np.abs(Pxy - g["Pxy"])) <= 3e-4 * np.abs(g["Pxy"]).max()
     np.testing.assert_allclose(Cxy, g["Cxy"], rtol=5e-3, atol=5e-4)
     assert np.max(np.abs(info.Rxy - g["info_Rxy"])) <= 5e-4 * np.abs(g["info_Rxy"]).max()
+
+
+def test_fftanal_fftpwelch_usemlab():
+    """the class path hands useMLAB through to fft_pwelch (fft_analysis.py:1796-1803)"""
+    import pyfft_amd as P
+    g = load_golden("pwelch_usemlab_onesided")
+    t, x, y = g["t"], g["x"], g["y"]
+    ft = P.fftanal(t, x, y, tbounds=[t[0], t[-2]], Navr=15, windowoverlap=0.5, windowfunction="Hamming", useMLAB=True,
+                   plotit=False, verbose=False)
+    ft.fftpwelch()
+    assert np.max(np.abs(ft.Pxx - g["Pxx"])) <= 3e-4 * np.abs(g["Pxx"]).max()
+    assert np.max(np.abs(ft.Pxy - g["Pxy"])) <= 3e-4 * np.abs(g["Pxy"]).max()
+    with pytest.raises(NotImplementedError):
+        ft.stft()
