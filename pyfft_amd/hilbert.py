@@ -14,7 +14,9 @@ def hilbert(uin, nfft=None, axes=-1):
     reference.  float32 input -> complex64 result (numpy>=2 behaviour of the reference), otherwise complex128."""
     u = np.atleast_1d(np.asarray(uin))
     if np.iscomplexobj(u):
-        raise NotImplementedError("hilbert of a complex input is not on the device path")
+        # FFT -> mask -> IFFT is linear: the complex case is the real kernel on both parts
+        out_c = np.complex64 if u.dtype == np.complex64 else np.complex128
+        return (hilbert(u.real, nfft, axes) + 1j * hilbert(u.imag, nfft, axes)).astype(out_c)
     if nfft is None:
         nfft = u.shape[axes]
     nfft = int(nfft)
@@ -29,6 +31,9 @@ def hilbert(uin, nfft=None, axes=-1):
 def hilbert_1d(uin, nfft=None):
     """1-D variant (hilbert.py:70-112); same mask, no squeeze."""
     u = np.atleast_1d(np.asarray(uin))
+    if np.iscomplexobj(u):
+        out_c = np.complex64 if u.dtype == np.complex64 else np.complex128
+        return (hilbert_1d(u.real, nfft) + 1j * hilbert_1d(u.imag, nfft)).astype(out_c)
     if nfft is None:
         nfft = len(u)
     return _E.hilbert_rows(np.ascontiguousarray(u[None, :]), int(nfft))[0].astype(_out_dtype(u))

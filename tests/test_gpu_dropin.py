@@ -383,3 +383,15 @@ def test_fftanal_fftpwelch_usemlab():
     assert np.max(np.abs(ft.Pxy - g["Pxy"])) <= 3e-4 * np.abs(g["Pxy"]).max()
     with pytest.raises(NotImplementedError):
         ft.stft()
+
+
+def test_hilbert_complex_input():
+    """complex input (the reference's code path has no real-only restriction): linearity of FFT -> mask -> IFFT"""
+    import pyfft_amd as P
+    rng = np.random.default_rng(9)
+    u = rng.standard_normal((3, 700)) + 1j * rng.standard_normal((3, 700))
+    z = P.hilbert(u)
+    ref = O.hilbert(u)
+    assert z.shape == ref.shape and np.max(np.abs(z - ref)) <= 2e-5 * np.abs(ref).max()
+    z1 = P.hilbert_1d(u[0])
+    assert np.max(np.abs(z1 - O.hilbert_1d(u[0]))) <= 2e-5 * np.abs(ref).max()
