@@ -113,3 +113,39 @@ def test_unsupported_branches_raise():
     t = np.arange(100.0)
     with pytest.raises(NotImplementedError):
         pyfft_amd.fft_pwelch(t, np.zeros(50), np.zeros(100))       # nT-model branch
+
+
+def test_named_window_catalogue_matches_reference():
+    """Named generators + get_window (reference windows.py:301-2425) against tables captured from the reference
+    (tests/golden/make_golden_windows.py).  Host table generation only: these feed the device as window tables."""
+    import ast
+    import importlib
+    W = importlib.import_module("pyfft_amd.windows")
+    g = load_golden("named_windows")
+    get_window_args = ["hann", "tri", "flt", "box", "bkh", ("tukey", 0.3), ("ggs", 1.5, 3.0), ("ksr", 5.0), 4.0,
+                       ("poisson", None, 2.0)]
+    n = 0
+    for k in g.files:
+        parts = k.split("|")
+        if parts[0] == "get_window":
+            got = W.get_window(get_window_args[int(parts[1])], 16, bool(int(parts[2])))
+        elif parts[0] == "dpss":
+            got = W.dpss(64, 2.5, 3)
+        else:
+            params = ast.literal_eval(parts[1])
+            got = getattr(W, parts[0])(int(parts[2]), *params, sym=bool(int(parts[3])))
+        assert got.shape == g[k].shape, k
+        np.testing.assert_allclose(got, g[k], rtol=0, atol=2e-15, err_msg=k)
+        n += 1
+    assert n > 250
+    with pytest.raises(ValueError):
+        W.hann(-1)
+    with pytest.raises(ValueError):
+        W.hann(2.5)
+    with pytest.raises(ValueError):
+        W.get_window("kaiser", 8)           # parametrised window given by bare name
+    with pytest.raises(ValueError):
+        W.get_window("nope", 8)
+    with pytest.raises(ValueError):
+        W.exponential(8, center=2, sym=True)
+    assert W.hanning is not None and set(W._win_equiv) >= {"hann", "tuk", "optimal", "dss"}
