@@ -139,6 +139,14 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
             int detrend, double mean_re, double mean_im, int sided, double amp_scale, int out_kind,
             int out_major, void *out, double *pseg_out, int mem);
 
+/* ---- N3: Doppler.cog applied per STFT frame (Doppler.py:43-58; the loop body of cogspec, Doppler.py:73-81):
+ *      cog_out[g] = sum_k f_k |X_g[k]|^2 / sum_k |X_g[k]|^2 over the two-sided spectrum of frame g, f_k = fftfreq(nfft, 1/fs),
+ *      restricted to fmin <= |f_k| <= fmax (fmin = 0, fmax >= fs/2: every bin); 0 where the band holds no power.  The
+ *      spectrogram is never written: the moments are reduced inside the transform kernel.  float64[nframes], follows `mem`.
+ *      Frame g = win * detrended x[g*hop : g*hop+nfft]; a boxcar window with SP_DETREND_CONST (0,0) is cog(x[frame], fs). */
+int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+                int detrend, double mean_re, double mean_im, double fs, double fmin, double fmax, double *cog_out, int mem);
+
 /* ---- A10: hilbert.hilbert / hilbert_1d (hilbert.py:22-112): rows of n_in real samples (row stride
  *      x_ld), transform length nfft (zero-pad / truncate like np.fft.fft(n=nfft)), one-sided mask with the
  *      reference's odd-length convention (bin nyq untouched), inverse; out[batch][nfft] complex64. */

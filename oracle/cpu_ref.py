@@ -543,6 +543,51 @@ def ccf_fft(x1, x2, fs):
 
 
 # --------------------------------------------------------------------------- #
+# N3  centre of gravity of a spectrum                         Doppler.py:43-81
+# --------------------------------------------------------------------------- #
+def cog(x, fs, fmin=None, fmax=None):
+    """Power-weighted mean frequency of the two-sided spectrum (Doppler.py:43-58).  With fmin given, the band's frequencies
+    are paired with the FIRST len(band) bins of the shifted spectrum: the reference's second mask is computed on the
+    already selected frequency axis (Doppler.py:53-54), and this restatement keeps that."""
+    if fmax is None:
+        fmax = fs
+    n = len(x)
+    freq = np.fft.fftshift(np.fft.fftfreq(n, 1 / fs))
+    spec = np.fft.fftshift(np.fft.fft(x)) / np.sqrt(n / 2)
+    if fmin is not None:
+        freq = freq[(np.abs(freq) >= fmin) & (np.abs(freq) <= fmax)]
+        spec = spec[:len(freq)]
+    if len(freq) > 0:
+        p = np.abs(spec) ** 2
+        return np.sum(p * freq) / np.sum(p)
+    return 0.0
+
+
+def cog_frames(t, x, fs, win=512, ov=0.5, fmin=None, fmax=None, window=None):
+    """The window loop of cogspec (Doppler.py:61-81) over the complete windows at hop floor((1-ov) win): tcog = mean time,
+    coge = cog of each window.  fmin/fmax here are a true band limit on |f| (not cog()'s pairing), window an optional
+    taper: the build-defined extensions of pyfft_amd.doppler.cog_frames."""
+    hop = int(np.floor((1.0 - ov) * win))
+    nframes = (len(x) - win) // hop + 1
+    freq = np.fft.fftfreq(win, 1 / fs)
+    keep = np.ones(win, dtype=bool)
+    if fmin is not None:
+        keep &= np.abs(freq) >= fmin
+    if fmax is not None:
+        keep &= np.abs(freq) <= fmax
+    w = np.ones(win) if window is None else np.asarray(window, dtype=np.float64)
+    tcog = np.zeros(nframes)
+    coge = np.zeros(nframes)
+    for g in range(nframes):
+        seg = np.asarray(x[g * hop:g * hop + win])
+        p = np.abs(np.fft.fft(w * seg)) ** 2 * keep          # float64 (the reference transforms complex64 in single)
+        den = p.sum()
+        coge[g] = (p * freq).sum() / den if den > 0 else 0.0
+        tcog[g] = np.mean(t[g * hop:g * hop + win])
+    return tcog, coge
+
+
+# --------------------------------------------------------------------------- #
 # A12  notch / peak biquad design                      notch_filter.py:175-241
 # --------------------------------------------------------------------------- #
 def _design_notch_peak(w0, Q, ftype):

@@ -18,3 +18,5 @@ from .hilbert import hilbert, hilbert_1d                     # noqa: F401
 from .ccf import ccf                                         # noqa: F401
 from .notch_filter import iirnotch, iirpeak, apply_notch     # noqa: F401
 from .filters import fftfilt                                 # noqa: F401
+from . import doppler                                        # noqa: F401   (Doppler.cog / cogspec window loop)
+from .doppler import cog, cog_frames                         # noqa: F401

@@ -4,10 +4,10 @@ namespace sp {
 
 int launch_stft(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
                 bool lin, const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg,
-                int segmean) {
+                int segmean, double *cog, int klo, int khi) {
 #define L_(XT, CP, LN)                                                                                \
     hipLaunchKernelGGL((k_stft<XT, CP, LN>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, win, hop, \
-                       nframes, rp.fpg, trend, xf.tb, sided, amp, out_power, out, pseg, segmean)
+                       nframes, rp.fpg, trend, xf.tb, sided, amp, out_power, out, pseg, segmean, cog, klo, khi)
 #define M_(XT)                                                                                        \
     if (cplx) {                                                                                       \
         if (lin) L_(XT, true, true);                                                                  \
@@ -40,6 +40,11 @@ int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64
         default: return -1;
     }
 #undef RP_
+    return 0;
+}
+
+int launch_cog_finish(LaunchCtx c, const double *acc, int64_t nframes, double df, double *out) {
+    hipLaunchKernelGGL(k_cog_finish, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, c.stream, acc, nframes, df, out);
     return 0;
 }
 

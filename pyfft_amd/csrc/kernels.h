@@ -1349,7 +1349,8 @@ template <class X, bool CPLX, bool LIN>
 __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, const float *__restrict__ win, int hop,
                                                     int64_t nframes, int64_t fpg, const float *__restrict__ trend,
                                                     XfTables tb, int sided, float amp, int out_power,
-                                                    void *__restrict__ out, double *__restrict__ pseg, int segmean) {
+                                                    void *__restrict__ out, double *__restrict__ pseg, int segmean,
+                                                    double *__restrict__ cog, int klo, int khi) {
     SP_KERNEL_PROLOGUE(X)
     float w[C::R];
 #pragma unroll
@@ -1381,6 +1382,32 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
         }
         if (pseg != nullptr && act) atomicAdd(&pseg[g], (double)pw);
         xf.fwd(v, lds, tid, n);
+        if (cog != nullptr) {
+            // centre of gravity of the frame's two-sided power spectrum (Doppler.py:43-58): moments sum |X|^2 ks and
+            // sum |X|^2 over the signed bin index ks = fftfreq(n) n, band klo <= |ks| <= khi; the caller divides
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int k = tid + C::T * t;
+                if (!X::EXACT && k >= n) continue;
+                const int ks = k < (n + 1) / 2 ? k : k - n;
+                const int ka = ks < 0 ? -ks : ks;
+                const float p = (ka >= klo && ka <= khi) ? cnorm(v[t]) : 0.f;
+                num += p * (float)ks;
+                den += p;
+            }
+            constexpr int W = C::T < 64 ? C::T : 64;       // lanes of one frame group inside a wave
+#pragma unroll
+            for (int o = W / 2; o > 0; o >>= 1) {
+                num += __shfl_xor(num, o);
+                den += __shfl_xor(den, o);
+            }
+            if ((tid & (W - 1)) == 0 && act) {
+                atomicAdd(&cog[2 * g], (double)num);
+                atomicAdd(&cog[2 * g + 1], (double)den);
+            }
+            continue;
+        }
         if (act) {
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
@@ -1397,6 +1424,14 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
             }
         }
     }
+}
+
+// cog[g] = df * num / den (0 where the band holds no power), in place over the moment pairs' first half
+static __global__ void k_cog_finish(const double *__restrict__ acc, int64_t nframes, double df, double *__restrict__ out) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nframes) return;
+    const double num = acc[2 * g], den = acc[2 * g + 1];
+    out[g] = den > 0.0 ? df * num / den : 0.0;
 }
 
 // Real input STFT, two frames per transform: z = f_g + i f_{g+1};  X_g = (Z[k] + conj Z[n-k]) / 2,

@@ -1235,6 +1235,60 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
     return 0;
 }
 
+int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+                int detrend, double mean_re, double mean_im, double fs, double fmin, double fmax, double *cog_out, int mem) {
+    if (ensure_init()) return -1;
+    if (check_frames("sp_stft_cog", nsig, nfft, hop, nframes)) return -1;
+    if (detrend < 0 || detrend > 4) return fail("sp_stft_cog: detrend must be 0..4");
+    if (!(fs > 0.0) || fmin < 0.0 || fmax < fmin) return fail("sp_stft_cog: need fs > 0 and 0 <= fmin <= fmax");
+    const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : (detrend == SP_DETREND_SEGLINEAR ? 2 : 0);
+    if (segmean) {
+        detrend = SP_DETREND_CONST;
+        mean_re = mean_im = 0.0;
+    }
+    std::lock_guard<std::mutex> lk(g.mu);
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
+    const bool cplx = x_dtype == SP_DTYPE_C64;
+    const size_t esz = cplx ? 8 : 4;
+    const void *xd = x;
+    if (!mem) {
+        if (g.in0.ensure(esz * (size_t)nsig)) return -1;
+        HIPCHK(hipMemcpyAsync(g.in0.p, x, esz * (size_t)nsig, hipMemcpyHostToDevice, g.stream));
+        xd = g.in0.p;
+    }
+    void *win_d;
+    if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
+    TrendBuf tb;
+    if (get_trendbuf(1, &tb)) return -1;
+    if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
+    // band in bins of df = fs/nfft: klo = ceil(fmin/df), khi = floor(fmax/df), with a relative guard against a frequency
+    // that is a bin centre up to rounding
+    const double df = fs / (double)nfft;
+    const double eps = 1e-9;
+    const int klo = (int)std::ceil(fmin / df - eps);
+    const double kh = std::floor(fmax / df + eps);
+    const int khi = kh > (double)nfft ? nfft : (int)kh;
+    const size_t abytes = sizeof(double) * 2 * (size_t)nframes;
+    if (g.work.ensure(abytes)) return -1;
+    double *acc = (double *)g.work.p;
+    double *fin = cog_out;
+    if (!mem) {
+        if (g.out0.ensure(sizeof(double) * (size_t)nframes)) return -1;
+        fin = (double *)g.out0.p;
+    }
+    HIPCHK(hipMemsetAsync(acc, 0, abytes, g.stream));
+    const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+    LAUNCHCHK(launch_stft(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, 2, 1.f, 1, nullptr,
+                          nullptr, segmean, acc, klo, khi));
+    LAUNCHCHK(launch_cog_finish(lc(), acc, nframes, df, fin));
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(cog_out, fin, sizeof(double) * (size_t)nframes, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
+}
+
 int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t batch, void *out, int mem) {
     if (ensure_init()) return -1;
     if (n_in < 1 || nfft < 2 || batch < 1 || x_ld < n_in) return fail("sp_hilbert: bad sizes");

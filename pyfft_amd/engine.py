@@ -371,6 +371,29 @@ def stft_frames(x, win, hop, nframes, detrend=True, sided=SIDED_ONE, amp_scale=1
     return out, pseg
 
 
+# ------------------------------------------------------------------------------------------ N3
+def stft_cog(x, win, hop, nframes, fs, fmin=0.0, fmax=None, detrend=False, mean_value=None):
+    """Centre of gravity (power-weighted mean frequency, Doppler.py:43-58) of every frame's two-sided spectrum, reduced
+    inside the transform kernel.  float64 [nframes]; band fmin <= |f| <= fmax (default: every bin)."""
+    w = _win32(win)
+    nfft = w.size
+    want, mv = _detrend_args(detrend, mean_value)
+    fmax = float(fs) if fmax is None else float(fmax)
+    if _is_torch(x):
+        _bind_stream(x)
+        xs = _torch_samples(x)
+        out = torch.empty(int(nframes), dtype=torch.float64, device=xs.device)
+        check(lib().sp_stft_cog(ptr(xs.data_ptr()), _tcode(xs), xs.numel(), ptr(w), nfft, int(hop), int(nframes), want,
+                                mv.real, mv.imag, float(fs), float(fmin), fmax, ptr(out.data_ptr()), 1))
+        return out
+    xs = _ffi.as_samples(x)
+    out = np.empty(int(nframes), dtype=np.float64)
+    _ffi.init()
+    check(lib().sp_stft_cog(ptr(xs), _ffi.dtype_code(xs.dtype), xs.size, ptr(w), nfft, int(hop), int(nframes), want,
+                            mv.real, mv.imag, float(fs), float(fmin), fmax, ptr(out), 0))
+    return out
+
+
 # ------------------------------------------------------------------------------------------ A10
 def hilbert_rows(x2d, nfft):
     """Analytic signal of each row of a real [batch, n_in] array, transform length nfft -> complex64 [batch, nfft]."""

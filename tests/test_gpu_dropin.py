@@ -395,3 +395,64 @@ def test_hilbert_complex_input():
     assert z.shape == ref.shape and np.max(np.abs(z - ref)) <= 2e-5 * np.abs(ref).max()
     z1 = P.hilbert_1d(u[0])
     assert np.max(np.abs(z1 - O.hilbert_1d(u[0]))) <= 2e-5 * np.abs(ref).max()
+
+
+# ---- N3: Doppler centre of gravity (Doppler.py:43-81) -----------------------------------------------------------------
+def test_doppler_cog_whole_vector(P):
+    """pyfft_amd.cog against values the reference's Doppler.cog produced (tests/golden/make_golden_doppler.py).  Tolerance:
+    float32 device transform; the real-input centre is a cancellation of +f against -f, so it is absolute in fs."""
+    g = load_golden("doppler_cog")
+    fs, z, r = float(g["fs"]), g["z"], g["r"]
+    for tag in ("4096", "1000", "40000", "16384"):          # one-workgroup (pow2, Bluestein) and long transforms
+        m = int(tag)
+        assert abs(P.cog(z[:m], fs) - float(g["cog_z_" + tag])) <= 2e-6 * fs, tag
+        assert abs(P.cog(r[:m], fs) - float(g["cog_r_" + tag])) <= 2e-6 * fs, tag
+    # band form: the reference's pairing of band frequencies with the leading bins
+    assert abs(P.cog(z[:4096], fs, fmin=50e3, fmax=200e3) - float(g["cog_z_band"])) <= 1e-5 * abs(float(g["cog_z_band"]))
+    assert abs(P.cog(z[:1000], fs, fmin=100e3) - float(g["cog_z_band_nofmax"])) <= 1e-5 * abs(float(g["cog_z_band_nofmax"]))
+    assert P.cog(z[:1000], fs, fmin=2e6, fmax=3e6) == 0.0
+
+
+@pytest.mark.parametrize("tag,win,ov", [("512", 512, 0.5), ("200", 200, 0.75)])
+def test_doppler_cog_frames(P, tag, win, ov):
+    """the window loop of cogspec: every complete window's cog from the fused kernel vs the reference's cog per window"""
+    g = load_golden("doppler_cog")
+    fs, z, r = float(g["fs"]), g["z"], g["r"]
+    t = np.arange(len(z)) / fs
+    tc, cg = P.cog_frames(t, z, fs, win=win, ov=ov)
+    assert cg.dtype == np.float64 and cg.shape == g["frames_z_" + tag].shape
+    np.testing.assert_allclose(tc, O.cog_frames(t, z, fs, win=win, ov=ov)[0], rtol=1e-12)
+    np.testing.assert_allclose(cg, g["frames_z_" + tag], rtol=0, atol=2e-6 * fs)
+    tc, cg = P.cog_frames(t, r, fs, win=win, ov=ov)
+    np.testing.assert_allclose(cg, g["frames_r_" + tag], rtol=0, atol=2e-6 * fs)
+
+
+def test_doppler_cog_frames_band_window_and_device_tensor(P):
+    """build-defined extensions: true band limit, taper, device-resident input; checked against the oracle.  Plus the
+    size-independent property at a large size: a pure tone's centre of gravity is the tone."""
+    import torch
+    from pyfft_amd.windows import windows
+    g = load_golden("doppler_cog")
+    fs, z = float(g["fs"]), g["z"]
+    t = np.arange(len(z)) / fs
+    w = windows("hann", nwins=256, verbose=False)
+    for kw in (dict(fmin=60e3, fmax=250e3), dict(fmin=None, fmax=120e3), dict(window=w), dict(window=w, fmin=70e3, fmax=300e3)):
+        _, ref = O.cog_frames(t, z, fs, win=256, ov=0.5, **kw)
+        _, got = P.cog_frames(t, z, fs, win=256, ov=0.5, **kw)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=3e-6 * fs, err_msg=str(kw.keys()))
+    zt = torch.from_numpy(z).cuda()
+    _, got_t = P.cog_frames(t, zt, fs, win=256, ov=0.5)
+    _, got_h = P.cog_frames(t, z, fs, win=256, ov=0.5)
+    assert got_t.is_cuda and np.array_equal(got_t.cpu().numpy(), got_h)
+    # empty band -> 0, like cog()
+    _, e = P.cog_frames(t, z, fs, win=256, ov=0.5, fmin=0.6 * fs, fmax=0.7 * fs)
+    assert np.all(e == 0.0)
+    # 2^24 samples, 4096-point windows: tone at bin 333.0 of 4096 -> cog = 333/4096 fs in every window
+    n = 1 << 24
+    k = torch.arange(n, device="cuda", dtype=torch.float64)
+    tone = torch.exp(2j * np.pi * (333.0 / 4096.0) * k).to(torch.complex64)
+    _, cg = P.cog_frames(np.arange(n) / fs, tone, fs, win=4096, ov=0.5)
+    assert cg.shape == (n // 2048 - 1,)
+    np.testing.assert_allclose(cg.cpu().numpy(), 333.0 / 4096.0 * fs, rtol=0, atol=1e-5 * fs)
+    with pytest.raises(ValueError):
+        P.cog_frames(t, z, fs, win=1 << 20)

@@ -278,3 +278,24 @@ def test_fft_pwelch_usemlab_branch(tag, kw):
     for a, name in ((Pxx, "Pxx"), (Pyy, "Pyy"), (Pxy, "Pxy"), (Cxy, "Cxy")):
         assert np.max(np.abs(np.asarray(a) - g[name])) <= 1e-11 * np.abs(g[name]).max(), name
     np.testing.assert_allclose(info["Rxy"], g["info_Rxy"], rtol=1e-8, atol=1e-11 * np.abs(g["info_Rxy"]).max())
+
+
+def test_doppler_cog_against_reference_fixture():
+    """Doppler.cog (Doppler.py:43-58) whole-vector, banded (reference pairing) and per-window values"""
+    g = load_golden("doppler_cog")
+    fs, z, r = float(g["fs"]), g["z"], g["r"]
+    t = np.arange(len(z)) / fs
+    for tag in ("4096", "1000", "40000", "16384"):
+        m = int(tag)
+        np.testing.assert_allclose(O.cog(z[:m], fs), g["cog_z_" + tag], rtol=1e-10, atol=1e-7)
+        np.testing.assert_allclose(O.cog(r[:m], fs), g["cog_r_" + tag], rtol=1e-8, atol=1e-6)
+    np.testing.assert_allclose(O.cog(z[:4096], fs, fmin=50e3, fmax=200e3), g["cog_z_band"], rtol=1e-10)
+    np.testing.assert_allclose(O.cog(z[:1000], fs, fmin=100e3), g["cog_z_band_nofmax"], rtol=1e-10)
+    assert O.cog(z[:1000], fs, fmin=2e6, fmax=3e6) == float(g["cog_z_band_empty"]) == 0.0
+    for tag, win, ov in (("512", 512, 0.5), ("200", 200, 0.75)):
+        tc, cg = O.cog_frames(t, z, fs, win=win, ov=ov)
+        # numpy transforms the complex64 / float32 frames in single precision in the reference; cog_frames works in double
+        np.testing.assert_allclose(cg, g["frames_z_" + tag], rtol=1e-7, atol=1e-6)
+        np.testing.assert_allclose(tc, g["frames_t_" + tag], rtol=1e-12)
+        tc, cg = O.cog_frames(t, r, fs, win=win, ov=ov)
+        np.testing.assert_allclose(cg, g["frames_r_" + tag], rtol=1e-6, atol=1e-7 * fs)

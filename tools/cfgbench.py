@@ -37,7 +37,7 @@ def report(name, ms, alg_bytes, units, unit_name):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="cfg2,cfg3,cfg4,cfg5,hilbert,xcorr")
+    ap.add_argument("--only", default="cfg2,cfg3,cfg4,cfg5,hilbert,xcorr,cog")
     ap.add_argument("--reps", type=int, default=5)
     a = ap.parse_args()
     only = set(a.only.split(","))
@@ -105,6 +105,14 @@ def main():
         ms, co = timed(lambda: E.xcorr_normalised(x1, x2), 3)
         report("ccf 2^24 samples (2^25-1 lags)", ms, 16.0 * n, n, "samples")
         print("     argmax lag = %d (expected -100)" % (int(torch.argmax(co)) - (n - 1)))
+
+    if "cog" in only:       # N3: centre of gravity per frame, metric shape (2^28 complex64, 4096-point windows, 50 % overlap)
+        n, nfft, hop = 1 << 28, 4096, 2048
+        x = torch.view_as_complex(torch.randn((n, 2), generator=g, device=dev, dtype=torch.float32))
+        M = (n - nfft) // hop + 1
+        ms, cg = timed(lambda: E.stft_cog(x, np.ones(nfft), hop, M, 1.0e6), a.reps)
+        report("cog per frame 2^28 c64 n4096 ov50", ms, 8.0 * n + 8.0 * M, n, "samples")
+        del x
 
 
 if __name__ == "__main__":
