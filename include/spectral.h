@@ -152,6 +152,13 @@ int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int 
  *      reference's odd-length convention (bin nyq untouched), inverse; out[batch][nfft] complex64. */
 int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t batch, void *out, int mem);
 
+/* ---- N4: frequency-domain response applied to real rows: out = IFFT(H * FFT(x, nfft)) -- the transform pair of
+ *      fft_deriv (fft_analysis.py:1526-1546: `real(ifft(wavenumber * fft(sig)))`), the Hilbert kernel with the mask
+ *      replaced by a table.  H: complex64[nfft], always a HOST array (like the window tables); x rows of n_in real
+ *      samples (row stride x_ld), zero-padded / truncated to nfft; out[batch][nfft] complex64 (x, out follow `mem`). */
+int sp_spectral_filter(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t batch, const void *H, void *out,
+                       int mem);
+
 /* ---- A11: ccf.ccf (ccf.py:66-77): normalised cross-covariance of two real length-n signals at all
  *      2n-1 lags, via zero-padded FFTs; co_out[2n-1] float32 in np.correlate(...,'full') order. */
 int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem);

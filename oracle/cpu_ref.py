@@ -543,6 +543,39 @@ def ccf_fft(x1, x2, fs):
 
 
 # --------------------------------------------------------------------------- #
+# N4  derivative by FFT                              fft_analysis.py:1419-1587
+# --------------------------------------------------------------------------- #
+def fft_deriv(sig, xx=None, modified=True, detrend=None, window=None):
+    """real(ifft(wavenumber * fft(win * scaled sig))) / win with one-sided differences at the two ends, on the scaled
+    axes of rescale()/unscale() (fft_analysis.py:1419-1451, :1514-1565).  The lowpass/downsample branch (:1494-1509) is
+    a no-op for the default arguments (Fs_new == Fs) and is not restated."""
+    sig = np.asarray(sig, dtype=np.float64)
+    xx = 1.0 * np.arange(len(sig)) if xx is None else np.asarray(xx, dtype=np.float64)
+    slope = sig.max() - sig.min()
+    offset = sig.min()
+    slope = slope if slope != 0 else 1.0
+    xslope = xx.max() - xx.min()
+    xslope = xslope if xslope != 0 else 1.0
+    xoffset = -1e-4
+    y = (sig - offset) / slope
+    x = (xx - xoffset) / xslope
+    if detrend is not None:
+        y = detrend(y)
+    N = len(x)
+    dx = x[1] - x[0]
+    L = N * dx
+    k = 2.0 * np.pi * np.fft.fftfreq(N, d=dx / L)
+    wn = (1j * np.sin(k * dx) / dx if modified else 1j * k) / L
+    win = np.ones(N) if window is None else window(N)
+    y = win * y
+    d0 = (y[1] - y[0]) / (x[1] - x[0])
+    d1 = (y[-1] - y[-2]) / (x[-1] - x[-2])
+    d = np.real(np.fft.ifft(wn * np.fft.fft(y))) / win
+    d[0], d[-1] = d0, d1
+    return d * slope / xslope, x * xslope + xoffset
+
+
+# --------------------------------------------------------------------------- #
 # N3  centre of gravity of a spectrum                         Doppler.py:43-81
 # --------------------------------------------------------------------------- #
 def cog(x, fs, fmin=None, fmax=None):

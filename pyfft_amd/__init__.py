@@ -13,6 +13,7 @@ from . import fft_analysis as fft       # noqa: F401   (reference: `import fft_a
 from . import spectrogram, hilbert as _hilbert_mod, ccf as _ccf_mod, filters, notch_filter   # noqa: F401
 from .windows import windows            # noqa: F401
 from .fft_analysis import fft_pwelch, fftanal, Cxy_Cxy2, psd, csd, coh, coh2     # noqa: F401
+from .fft_analysis import detrend_none, detrend_mean, detrend_linear, unwrap_tol, fft_deriv   # noqa: F401  (__init__.py:22-23)
 from .spectrogram import specgram, stft                      # noqa: F401
 from .hilbert import hilbert, hilbert_1d                     # noqa: F401
 from .ccf import ccf                                         # noqa: F401

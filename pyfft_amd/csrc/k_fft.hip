@@ -59,11 +59,12 @@ int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B
     return 0;
 }
 
-int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out) {
+int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out,
+                   const cf *H) {
     const int blocks = strided_blocks(xf.L, batch, c.ncu);
 #define M_(XT)                                                                                        \
     hipLaunchKernelGGL((k_hilbert<XT>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n_in, x_ld, \
-                       batch, xf.tb, out);
+                       batch, xf.tb, out, H);
     SP_DISPATCH_X(xf, M_)
 #undef M_
     return 0;
@@ -171,6 +172,10 @@ int launch_blue_post(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int 
 }
 int launch_hilbert_mask(LaunchCtx c, cf *X, int64_t n) {
     hipLaunchKernelGGL(k_hilbert_mask, dim3(ew_blocks(n, c.ncu)), dim3(256), 0, c.stream, X, n);
+    return 0;
+}
+int launch_spec_mul(LaunchCtx c, cf *X, const cf *H, int64_t n) {
+    hipLaunchKernelGGL(k_spec_mul, dim3(ew_blocks(n, c.ncu)), dim3(256), 0, c.stream, X, H, n);
     return 0;
 }
 int launch_xc_pack(LaunchCtx c, const float *x1, const float *x2, int64_t n, int64_t L, const double *mom, cf *z) {

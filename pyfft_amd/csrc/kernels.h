@@ -1600,6 +1600,11 @@ static __global__ void k_hilbert_mask(cf *__restrict__ X, int64_t n) {
         X[k] = h * X[k];
     }
 }
+// X[k] *= H[k] in place (long-row form of sp_spectral_filter)
+static __global__ void k_spec_mul(cf *__restrict__ X, const cf *__restrict__ H, int64_t n) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)
+        X[k] = cmul(X[k], H[k]);
+}
 // z = (x1-m1) + i (x2-m2), zero-padded to L;  mom[0]=m1, mom[1]=m2
 static __global__ void k_xc_pack(const float *__restrict__ x1, const float *__restrict__ x2, int64_t n, int64_t L,
                                  const double *__restrict__ mom, cf *__restrict__ z) {
@@ -2059,9 +2064,12 @@ static __global__ void k_csdm_mirror(double *__restrict__ G, int nch, int nb, in
 // workgroup per row.  nyq = n/2 (even) or (n+1)/2 (odd): for odd n bin `nyq` is left untouched,
 // exactly as the reference does (Q6).
 // ------------------------------------------------------------------------------------------
+// H != nullptr: the spectrum is multiplied by the table H[0:n] instead of the mask (sp_spectral_filter: fft_deriv's
+// wavenumber, fft_analysis.py:1526-1546, or any other frequency response).
 template <class X>
 __global__ __launch_bounds__(X::C::WG) void k_hilbert(const float *__restrict__ x, int64_t n_in, int64_t x_ld,
-                                                       int64_t batch, XfTables tb, cf *__restrict__ out) {
+                                                       int64_t batch, XfTables tb, cf *__restrict__ out,
+                                                       const cf *__restrict__ H) {
     SP_KERNEL_PROLOGUE(X)
     const int nyq = nyq_of(n);
     const float inv = 1.f / (float)n;
@@ -2081,8 +2089,14 @@ __global__ __launch_bounds__(X::C::WG) void k_hilbert(const float *__restrict__ 
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int k = tid + C::T * t;
-            const float h = (k == 0 || k == nyq) ? 1.f : (k < nyq ? 2.f : 0.f);
-            v[t] = mk(h * v[t].x, -h * v[t].y);          // mask, then conj for the inverse
+            if (H != nullptr) {
+                const bool in = X::EXACT || k < n;
+                const cf p = cmul(v[t], H[in ? k : 0]);
+                v[t] = in ? mk(p.x, -p.y) : mk(0.f, 0.f);   // response, then conj for the inverse
+            } else {
+                const float h = (k == 0 || k == nyq) ? 1.f : (k < nyq ? 2.f : 0.f);
+                v[t] = mk(h * v[t].x, -h * v[t].y);      // mask, then conj for the inverse
+            }
         }
         xf.fwd(v, lds, tid, n);
         if (act) {

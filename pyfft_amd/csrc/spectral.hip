@@ -1331,6 +1331,48 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
     return 0;
 }
 
+int sp_spectral_filter(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t batch, const void *H, void *out,
+                       int mem) {
+    if (ensure_init()) return -1;
+    if (n_in < 1 || nfft < 2 || batch < 1 || x_ld < n_in || H == nullptr) return fail("sp_spectral_filter: bad sizes");
+    std::lock_guard<std::mutex> lk(g.mu);
+    const float *xd = x;
+    cf *od = (cf *)out;
+    const size_t ibytes = sizeof(float) * (size_t)x_ld * (size_t)batch;
+    const size_t obytes = sizeof(cf) * (size_t)nfft * (size_t)batch;
+    const size_t hbytes = sizeof(cf) * (size_t)nfft;
+    if (!mem) {
+        if (g.in0.ensure(ibytes) || g.out0.ensure(obytes)) return -1;
+        HIPCHK(hipMemcpyAsync(g.in0.p, x, ibytes, hipMemcpyHostToDevice, g.stream));
+        xd = (const float *)g.in0.p;
+        od = (cf *)g.out0.p;
+    }
+    const int64_t nuse = n_in < nfft ? n_in : nfft;
+    if (wg_capable(nfft)) {
+        Xf xf;
+        if (get_xf(nfft, &xf)) return -1;
+        void *H_d;
+        if (get_table(4, H, hbytes, &H_d, nullptr)) return -1;          // the response table is a host array (like win)
+        LAUNCHCHK(launch_hilbert(lc(), xd, nuse, x_ld, batch, xf, od, (const cf *)H_d));   // fwd, x H, inverse: one workgroup per row
+    } else {
+        if (g.bigA.ensure(sizeof(cf) * (size_t)nfft) || g.bigB.ensure(hbytes)) return -1;
+        cf *A = (cf *)g.bigA.p, *Hd = (cf *)g.bigB.p;
+        HIPCHK(hipMemcpyAsync(Hd, H, hbytes, hipMemcpyHostToDevice, g.stream));
+        for (int64_t b = 0; b < batch; ++b) {
+            LAUNCHCHK(launch_pack_real(lc(), xd + b * x_ld, nuse, nullptr, nfft, A));
+            if (dev_fft_any(A, A, nfft, 1, 0)) return -1;
+            LAUNCHCHK(launch_spec_mul(lc(), A, Hd, nfft));
+            if (dev_fft_any(A, od + b * nfft, nfft, 1, 1)) return -1;
+        }
+        HIPCHK(hipStreamSynchronize(g.stream));        // H was read from the caller's host array
+    }
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(out, od, obytes, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
+}
+
 int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem) {
     if (ensure_init()) return -1;
     if (n < 1) return fail("sp_xcorr: n must be positive");

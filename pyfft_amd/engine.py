@@ -412,6 +412,26 @@ def hilbert_rows(x2d, nfft):
     return out
 
 
+# ------------------------------------------------------------------------------------------ N4
+def spectral_filter_rows(x2d, H):
+    """IFFT(H * FFT(row)) for each real row of [batch, n]; H complex [n] (host table).  complex64 [batch, n]."""
+    Hc = np.ascontiguousarray(H, dtype=np.complex64)
+    nfft = Hc.size
+    if _is_torch(x2d):
+        _bind_stream(x2d)
+        xs = x2d.to(torch.float32).contiguous()
+        batch, n_in = xs.shape
+        out = torch.empty((batch, nfft), dtype=torch.complex64, device=xs.device)
+        check(lib().sp_spectral_filter(ptr(xs.data_ptr()), n_in, n_in, nfft, batch, ptr(Hc), ptr(out.data_ptr()), 1))
+        return out
+    xs = np.ascontiguousarray(x2d, dtype=np.float32)
+    batch, n_in = xs.shape
+    out = np.empty((batch, nfft), dtype=np.complex64)
+    _ffi.init()
+    check(lib().sp_spectral_filter(ptr(xs), n_in, n_in, nfft, batch, ptr(Hc), ptr(out), 0))
+    return out
+
+
 # ------------------------------------------------------------------------------------------ A11
 def xcorr_normalised(x1, x2):
     """co[2n-1] = correlate(x1-m1, x2-m2, 'full') / (n std1 std2), float32."""

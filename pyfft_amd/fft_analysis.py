@@ -7,7 +7,7 @@ window tables and the O(nfft) epilogue algebra stay on the host in float64, as i
 
 Deliberately not carried over (outside the hot-path scope): plotting (`plotit` is accepted
 and ignored), the matplotlib.mlab branch (`useMLAB=True` raises), the nT-model branch (sigx shorter than sigy),
-Monte-Carlo uncertainty helpers, integratespectra/getNpeaks/fft_deriv.
+Monte-Carlo uncertainty helpers, integratespectra/getNpeaks.
 """
 import numpy as np
 
@@ -318,6 +318,116 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
 # sum(w^2), one-sided doubling except DC and Nyquist, mean over segments) runs on the device through welch_psd /
 # welch_csd; only the band selection stays on the host.  Real input (the reference's use).
 # ------------------------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------
+# detrend handles (reference: pybaseutils.utils.detrend_*, imported at fft_analysis.py:23 and re-exported by the
+# package; that source is absent, the semantics -- along axis 0, like matplotlib.mlab.detrend_* -- are SURVEY 8c's
+# stated assumption) and the derivative by FFT (fft_analysis.py:1399-1587)
+# ------------------------------------------------------------------------------------------
+def detrend_none(x, axis=0):
+    return x
+
+
+def detrend_mean(x, axis=0):
+    x = np.asarray(x)
+    return x - x.mean(axis=axis, keepdims=True)
+
+
+def detrend_linear(x, axis=0):
+    x = np.asarray(x, dtype=np.float64 if not np.iscomplexobj(x) else np.complex128)
+    n = x.shape[axis]
+    k = np.arange(n, dtype=np.float64) - 0.5 * (n - 1)
+    shape = [1] * x.ndim
+    shape[axis] = n
+    k = k.reshape(shape)
+    slope = (x * k).sum(axis=axis, keepdims=True) / (k * k).sum()
+    return x - x.mean(axis=axis, keepdims=True) - slope * k
+
+
+def unwrap_tol(data, scal=np.pi, atol=None, rtol=None, itol=None):
+    """Phase unwrapping with a tolerance on the jump size (fft_analysis.py:1399-1408); modifies and returns `data`."""
+    if atol is None and rtol is None:
+        atol = 0.2
+    if atol is None and rtol is not None:
+        atol = rtol * scal
+    if itol is None:
+        itol = 1
+    tt = np.arange(len(data))
+    ti = tt[::itol]
+    jumps = np.diff(data[::itol]) / scal
+    jumps = np.sign(jumps) * np.floor(np.abs(jumps) + atol)
+    data[1:] = data[1:] - np.interp(tt[1:], ti[1:], scal * np.cumsum(jumps))
+    return data
+
+
+def rescale(xx, yy, scaley=True, scalex=True):
+    """Map y to [0, 1] and x to unit span (fft_analysis.py:1419-1438). -> xx, yy, (slope, offset, xslope, xoffset)"""
+    slope, offset, xslope, xoffset = 1.0, 0.0, 1.0, 0.0
+    if scaley:
+        slope = np.nanmax(yy) - np.nanmin(yy)
+        offset = np.nanmin(yy)
+        if slope == 0:
+            slope = 1.0
+        yy = (np.array(yy, copy=True) - offset) / slope
+    if scalex:
+        xslope = np.nanmax(xx) - np.nanmin(xx)
+        xoffset = -1e-4
+        if xslope == 0:
+            xslope = 1.0
+        xx = (np.array(xx, copy=True) - xoffset) / xslope
+    return xx, yy, (slope, offset, xslope, xoffset)
+
+
+def unscale(xx, yy, scl, dydx=None):
+    """Inverse of rescale (fft_analysis.py:1440-1451)."""
+    slope, offset, xslope, xoffset = scl
+    xx = xx * xslope + xoffset
+    yy = slope * yy + offset
+    if dydx is not None:
+        return xx, yy, dydx * slope / xslope
+    return xx, yy
+
+
+def fft_deriv(sig, xx=None, lowpass=True, Fs_new=None, modified=True, detrend=detrend_none, window=None):
+    """dsig/dx by FFT: real(ifft(wavenumber * fft(sig))) with the modified wavenumber j sin(k dx)/dx (or j k), end points
+    replaced by one-sided differences (fft_analysis.py:1453-1587).  -> (dsdx, xx)
+
+    The transform pair runs on the device in one fused kernel (sp_spectral_filter: forward FFT, times the wavenumber table,
+    inverse FFT); scaling, detrend handle, window table and the two end points are O(n) host work in float64 as in the
+    reference.  The pre-filter/downsample branch (Fs_new below the sampling rate) needs filters.downsample_efficient,
+    which depends on the absent pybaseutils.interp, and raises."""
+    sig = np.asarray(sig, dtype=np.float64)
+    if xx is None:
+        xx = 1.0 * np.arange(len(sig))
+    xx = np.asarray(xx, dtype=np.float64)
+    if lowpass:
+        dxo = xx[1] - xx[0]
+        if lowpass is True:
+            lowpass = 0.5 * 1.0 / dxo
+        Fs = 1.0 / dxo
+        if Fs_new is None:
+            Fs_new = min(5.0 * lowpass, Fs)
+        if Fs_new < Fs:
+            raise NotImplementedError("fft_deriv: the downsampling pre-filter (filters.downsample_efficient) needs "
+                                      "pybaseutils.interp, absent from the reference")
+    xx, sig, scl = rescale(xx, sig, scaley=True, scalex=True)
+    sig = detrend(sig)
+    N = len(xx)
+    dx = xx[1] - xx[0]
+    L = N * dx
+    k = 2.0 * np.pi * np.fft.fftfreq(N, d=dx / L)
+    wavenumber = (1.0j * np.sin(k * dx) / dx if modified else 1.0j * k) / L
+    win = np.ones_like(sig) if window is None else window(N)
+    sig = win * sig
+    ds0 = (sig[1] - sig[0]) / (xx[1] - xx[0])
+    ds1 = (sig[-1] - sig[-2]) / (xx[-1] - xx[-2])
+    d = _E.spectral_filter_rows(sig[None, :], wavenumber)[0].real.astype(np.float64)
+    d /= win
+    d[0] = ds0
+    d[-1] = ds1
+    xx, _, d = unscale(xx, d.copy(), scl=scl, dydx=d)
+    return d, xx
+
+
 def _mlab_detrend_code(detrend):
     if detrend in (None, "none", False):
         return False

@@ -456,3 +456,50 @@ def test_doppler_cog_frames_band_window_and_device_tensor(P):
     np.testing.assert_allclose(cg.cpu().numpy(), 333.0 / 4096.0 * fs, rtol=0, atol=1e-5 * fs)
     with pytest.raises(ValueError):
         P.cog_frames(t, z, fs, win=1 << 20)
+
+
+# ---- N4: derivative by FFT (fft_analysis.py:1453-1587) ------------------------------------------------------------------
+def test_fft_deriv_golden(P):
+    """pyfft_amd.fft_deriv against the reference's outputs on the inputs of its own test_fft_deriv.  Tolerance: the
+    wavenumber multiplies float32 rounding noise by up to 1/dx = N on the scaled axis, so atol = 2e-7 * N * max|d| floor
+    1e-4 * max|d| (the end points are exact one-sided differences)."""
+    from golden.make_golden_deriv import cases
+    g = load_golden("fft_deriv")
+    for name, (yy, xx, kw) in cases().items():
+        d, xo = P.fft_deriv(yy, xx, **kw)
+        ref = g[name + "_d"]
+        assert d.shape == ref.shape and d.dtype == np.float64, name
+        scale = np.max(np.abs(ref))
+        tol = max(1e-4, 2e-7 * len(yy)) * scale
+        assert np.max(np.abs(d - ref)) <= tol, (name, np.max(np.abs(d - ref)), tol)
+        assert d[0] == pytest.approx(ref[0], rel=1e-9, abs=1e-12 * scale) and d[-1] == pytest.approx(ref[-1], rel=1e-9, abs=1e-12 * scale)
+        if name + "_x" in g.files:
+            np.testing.assert_allclose(xo, g[name + "_x"], rtol=1e-12, atol=1e-12)
+    yy, xx, _ = cases()["sine_aperiodic"]
+    d, _ = P.fft_deriv(yy, xx, detrend=P.detrend_mean)
+    ref = g["sine_aperiodic_detrend_d"]
+    assert np.max(np.abs(d - ref)) <= 4e-4 * np.max(np.abs(ref))
+    with pytest.raises(NotImplementedError):
+        P.fft_deriv(yy, xx, lowpass=0.01)                    # would need the absent downsampling pre-filter
+
+
+def test_spectral_filter_rows_vs_numpy(P):
+    """sp_spectral_filter = IFFT(H FFT(x)): batched rows, zero-padding, Bluestein and long rows, device tensors"""
+    import torch
+    rng = np.random.default_rng(5)
+    for n, batch in ((256, 7), (1000, 3), (4096, 64), (8192, 2), (30000, 1), (1 << 17, 2)):
+        x = rng.standard_normal((batch, n)).astype(np.float32)
+        H = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        ref = np.fft.ifft(H[None, :] * np.fft.fft(x.astype(np.float64), axis=-1), axis=-1)
+        got = P.engine.spectral_filter_rows(x, H)
+        assert got.shape == ref.shape and got.dtype == np.complex64
+        err = np.max(np.abs(got - ref)) / np.max(np.abs(ref))
+        assert err <= 5e-6, (n, err)
+        got_t = P.engine.spectral_filter_rows(torch.from_numpy(x).cuda(), H)
+        assert np.array_equal(got_t.cpu().numpy(), got), n
+    # H = analytic-signal mask reproduces hilbert()
+    x = rng.standard_normal((4, 2048)).astype(np.float32)
+    h = np.zeros(2048)
+    h[0] = h[1024] = 1.0
+    h[1:1024] = 2.0
+    np.testing.assert_allclose(P.engine.spectral_filter_rows(x, h), P.engine.hilbert_rows(x, 2048), rtol=0, atol=1e-6)

@@ -113,8 +113,8 @@ def test_hilbert_edge_shapes(P):
     assert z.shape == (16,)
     np.testing.assert_allclose(P.hilbert(np.array([1.0, -1.0])), O.hilbert(np.array([1.0, -1.0])), atol=1e-6)
     np.testing.assert_allclose(P.hilbert(np.arange(5.0)), O.hilbert(np.arange(5.0)), atol=2e-6)     # odd quirk
-    with pytest.raises(NotImplementedError):
-        P.hilbert(np.ones(8) + 1j)
+    zc = np.arange(8.0) + 1j * np.cos(np.arange(8.0))        # complex input: by linearity, like the reference's fft/ifft
+    np.testing.assert_allclose(P.hilbert(zc), O.hilbert(zc), atol=5e-6)
 
 
 def test_long_fft_two_pass_option_matches(monkeypatch):

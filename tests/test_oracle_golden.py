@@ -299,3 +299,18 @@ def test_doppler_cog_against_reference_fixture():
         np.testing.assert_allclose(tc, g["frames_t_" + tag], rtol=1e-12)
         tc, cg = O.cog_frames(t, r, fs, win=win, ov=ov)
         np.testing.assert_allclose(cg, g["frames_r_" + tag], rtol=1e-6, atol=1e-7 * fs)
+
+
+def test_fft_deriv_against_reference_fixture():
+    """fft_deriv (fft_analysis.py:1453-1587) on the inputs of the reference's own test_fft_deriv"""
+    from golden.make_golden_deriv import cases
+    g = load_golden("fft_deriv")
+    for name, (yy, xx, kw) in cases().items():
+        d, xo = O.fft_deriv(yy, xx, **kw)
+        scale = np.max(np.abs(g[name + "_d"]))
+        np.testing.assert_allclose(d, g[name + "_d"], rtol=0, atol=1e-9 * scale, err_msg=name)
+        if name + "_x" in g.files:
+            np.testing.assert_allclose(xo, g[name + "_x"], rtol=1e-12, atol=1e-12, err_msg=name)
+    yy, xx, _ = cases()["sine_aperiodic"]
+    d, _ = O.fft_deriv(yy, xx, detrend=lambda v: v - v.mean())
+    np.testing.assert_allclose(d, g["sine_aperiodic_detrend_d"], rtol=0, atol=1e-9 * np.max(np.abs(d)))
