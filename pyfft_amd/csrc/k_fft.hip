@@ -63,8 +63,10 @@ int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int6
                    const cf *H) {
     const int blocks = strided_blocks(xf.L, batch, c.ncu);
 #define M_(XT)                                                                                        \
-    hipLaunchKernelGGL((k_hilbert<XT>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n_in, x_ld, \
-                       batch, xf.tb, out, H);
+    if (H) hipLaunchKernelGGL((k_hilbert<XT, true>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n_in, \
+                              x_ld, batch, xf.tb, out, H);                                            \
+    else hipLaunchKernelGGL((k_hilbert<XT, false>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n_in, \
+                            x_ld, batch, xf.tb, out, H);
     SP_DISPATCH_X(xf, M_)
 #undef M_
     return 0;

@@ -2064,9 +2064,9 @@ static __global__ void k_csdm_mirror(double *__restrict__ G, int nch, int nb, in
 // workgroup per row.  nyq = n/2 (even) or (n+1)/2 (odd): for odd n bin `nyq` is left untouched,
 // exactly as the reference does (Q6).
 // ------------------------------------------------------------------------------------------
-// H != nullptr: the spectrum is multiplied by the table H[0:n] instead of the mask (sp_spectral_filter: fft_deriv's
+// RESP: the spectrum is multiplied by the table H[0:n] instead of the mask (sp_spectral_filter: fft_deriv's
 // wavenumber, fft_analysis.py:1526-1546, or any other frequency response).
-template <class X>
+template <class X, bool RESP>
 __global__ __launch_bounds__(X::C::WG) void k_hilbert(const float *__restrict__ x, int64_t n_in, int64_t x_ld,
                                                        int64_t batch, XfTables tb, cf *__restrict__ out,
                                                        const cf *__restrict__ H) {
@@ -2089,7 +2089,7 @@ __global__ __launch_bounds__(X::C::WG) void k_hilbert(const float *__restrict__ 
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int k = tid + C::T * t;
-            if (H != nullptr) {
+            if constexpr (RESP) {
                 const bool in = X::EXACT || k < n;
                 const cf p = cmul(v[t], H[in ? k : 0]);
                 v[t] = in ? mk(p.x, -p.y) : mk(0.f, 0.f);   // response, then conj for the inverse
