@@ -152,6 +152,14 @@ int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int 
  *      reference's odd-length convention (bin nyq untouched), inverse; out[batch][nfft] complex64. */
 int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t batch, void *out, int mem);
 
+/* ---- A5, nT-model branch of fft_pwelch (fft_analysis.py:169-176, :346-393: a one-window model signal against every
+ *      window of the long channels): out[ch][n] = sum_g detrended(x[ch][g*hop + n]), n < nfft -- the time-domain sum of
+ *      all frames, from which sum_g FFT(win * frame_g) = FFT(win * out) follows by linearity (no spectrum is written).
+ *      nch channels with row stride x_ld; detrend 0 none, 1 each channel's mean over [0:nsig], 2 its least-squares line;
+ *      out float64 [nch][nfft][2] (re, im), follows `mem`. */
+int sp_frame_sum(const void *x, int x_dtype, int64_t nsig, int nch, int64_t x_ld, int nfft, int hop, int64_t nframes,
+                 int detrend, double *out, int mem);
+
 /* ---- N4: frequency-domain response applied to real rows: out = IFFT(H * FFT(x, nfft)) -- the transform pair of
  *      fft_deriv (fft_analysis.py:1526-1546: `real(ifft(wavenumber * fft(sig)))`), the Hilbert kernel with the mask
  *      replaced by a table.  H: complex64[nfft], always a HOST array (like the window tables); x rows of n_in real

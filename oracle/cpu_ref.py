@@ -296,11 +296,14 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
     if sigy.shape[1] == len(tvec):
         sigy = sigy.T
     nch = sigy.shape[1]
-    if sigx.shape[0] != sigy.shape[0]:
-        raise NotImplementedError("nTmodel branch (fft_analysis.py:170-176) is outside the hot-path scope")
-    if minFreq is not None:
-        tper = 2.0 / minFreq                                      # :180-181
-    if tper is not None:
+    nTmodel = sigx.shape[0] != sigy.shape[0]                      # :169-176: sigx is one window of a model signal
+    if nTmodel:
+        if not calcNavr:
+            raise UnboundLocalError("calcNavr")                   # the reference fails at :172 when Navr is given
+        nwins = sigx.shape[0]
+    elif minFreq is not None or tper is not None:
+        if minFreq is not None:
+            tper = 2.0 / minFreq                                  # :180-181
         nwins = int(Fs * tper)                                    # :183 (Q5)
     else:
         if Navr is None:
@@ -355,14 +358,14 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
                     ibnds=[i0, i1], win=win, reflecting=reflecting, minFreq=2.0 * Fs / nwins)
         return pwelch_epilogue(freq, Pxx, Pyy.real.T, Pxy.T, info, onesided)
 
-    x_in = detrend(sigx[i0:i1], detrend_style)                   # :353-357
+    x_in = detrend(sigx if nTmodel else sigx[i0:i1], detrend_style)   # :346-357 (nT-model: the whole one-window model)
     y_in = detrend(sigy[i0:i1, :], detrend_style)
     hop = nwins - noverlap
     Xfft = np.zeros((Navr, nfft), dtype=np.complex128)
     Yfft = np.zeros((nch, Navr, nfft), dtype=np.complex128)
     for g in range(Navr):                                         # :362-388
         a = g * hop
-        Xfft[g] = np.fft.fft(win * x_in[a:a + nwins], n=nfft, axis=0)
+        Xfft[g] = np.fft.fft(win * (x_in if nTmodel else x_in[a:a + nwins]), n=nfft, axis=0)   # :366-369
         Yfft[:, g, :] = np.fft.fft(win[:, None] * y_in[a:a + nwins, :], n=nfft, axis=0).T
     Pxx_seg = Xfft * np.conj(Xfft)                                # :391-393
     Pyy_seg = Yfft * np.conj(Yfft)

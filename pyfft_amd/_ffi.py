@@ -46,6 +46,7 @@ SIGNATURES = {
     "sp_stft": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i, _d, _d, _i, _d, _i, _i, _vp, _vp, _i]),
     "sp_stft_cog": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i, _d, _d, _d, _d, _d, _vp, _i]),
     "sp_hilbert": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _i]),
+    "sp_frame_sum": (_i, [_vp, _i, _i64, _i, _i64, _i, _i, _i64, _i, _vp, _i]),
     "sp_spectral_filter": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i]),
     "sp_xcorr": (_i, [_vp, _vp, _i64, _vp, _i]),
     "sp_fftfilt": (_i, [_vp, _i, _vp, _i64, _i, _vp, _i]),

@@ -1600,6 +1600,29 @@ static __global__ void k_hilbert_mask(cf *__restrict__ X, int64_t n) {
         X[k] = h * X[k];
     }
 }
+// c[ch][n] = sum_g detrended(x[ch][g*hop + n]), n < nfft: the time-domain sum of all frames of each channel.  By linearity
+// sum_g FFT(win * frame_g) = FFT(win * c): the mean spectrum of the nT-model branch of fft_pwelch (fft_analysis.py:346-393)
+// without writing one spectrum.  grid (ceil(nfft/256), frame slices, channels); float64 atomics into a zeroed out[ch][n][2].
+template <bool LIN>
+static __global__ void k_frame_sum(const void *__restrict__ x, int cplx, int64_t x_ld, int nfft, int hop, int64_t nframes,
+                                   const float *__restrict__ trend, double *__restrict__ out) {
+    const int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int ch = blockIdx.z;
+    const int64_t per = (nframes + gridDim.y - 1) / gridDim.y;
+    const int64_t g0 = (int64_t)blockIdx.y * per, g1 = g0 + per < nframes ? g0 + per : nframes;
+    if (n >= nfft || g0 >= g1) return;
+    const Trend tr = load_trend(trend + 4 * ch);
+    const int64_t off = (int64_t)ch * x_ld;
+    double sr = 0.0, si = 0.0;
+    for (int64_t g = g0; g < g1; ++g) {
+        const int64_t i = g * hop + n;
+        const cf v = detrended<LIN>(load_sample(x, off + i, cplx != 0), tr, i);
+        sr += (double)v.x;
+        si += (double)v.y;
+    }
+    atomicAdd(&out[2 * ((int64_t)ch * nfft + n)], sr);
+    atomicAdd(&out[2 * ((int64_t)ch * nfft + n) + 1], si);
+}
 // X[k] *= H[k] in place (long-row form of sp_spectral_filter)
 static __global__ void k_spec_mul(cf *__restrict__ X, const cf *__restrict__ H, int64_t n) {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x)

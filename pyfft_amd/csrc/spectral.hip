@@ -1331,6 +1331,47 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
     return 0;
 }
 
+int sp_frame_sum(const void *x, int x_dtype, int64_t nsig, int nch, int64_t x_ld, int nfft, int hop, int64_t nframes,
+                 int detrend, double *out, int mem) {
+    if (ensure_init()) return -1;
+    if (check_frames("sp_frame_sum", nsig, nfft, hop, nframes)) return -1;
+    if (nch < 1 || nch > 65535 || x_ld < nsig) return fail("sp_frame_sum: bad nch / x_ld");
+    if (detrend < 0 || detrend > 2) return fail("sp_frame_sum: detrend must be 0, 1 or 2");
+    std::lock_guard<std::mutex> lk(g.mu);
+    const bool cplx = x_dtype == SP_DTYPE_C64;
+    const size_t esz = cplx ? 8 : 4;
+    const void *xd = x;
+    const size_t ibytes = esz * ((size_t)x_ld * (size_t)(nch - 1) + (size_t)nsig);
+    const size_t obytes = sizeof(double) * 2 * (size_t)nfft * (size_t)nch;
+    if (!mem) {
+        if (g.in1.ensure(ibytes)) return -1;
+        HIPCHK(hipMemcpyAsync(g.in1.p, x, ibytes, hipMemcpyHostToDevice, g.stream));
+        xd = g.in1.p;
+    }
+    TrendBuf tb;
+    if (get_trendbuf(nch + 1, &tb)) return -1;
+    if (detrend != 0 && nch <= 512) {
+        double *scr = moments_scratch();
+        if (!scr) return -1;
+        LAUNCHCHK(launch_moments(lc(), xd, cplx, nsig, detrend, scr, tb.d + 8, tb.f + 4, nch, x_ld));
+    } else {
+        for (int c = 0; c < nch; ++c)
+            if (set_trend(tb, c + 1, (const char *)xd + esz * (size_t)x_ld * (size_t)c, cplx, nsig, detrend, 0, 0)) return -1;
+    }
+    double *od = out;
+    if (!mem) {
+        if (g.out0.ensure(obytes)) return -1;
+        od = (double *)g.out0.p;
+    }
+    HIPCHK(hipMemsetAsync(od, 0, obytes, g.stream));
+    LAUNCHCHK(launch_frame_sum(lc(), xd, cplx, x_ld, nch, nfft, hop, nframes, tb.f + 4, detrend == 2, od));
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(out, od, obytes, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
+}
+
 int sp_spectral_filter(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t batch, const void *H, void *out,
                        int mem) {
     if (ensure_init()) return -1;

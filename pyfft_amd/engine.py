@@ -412,6 +412,32 @@ def hilbert_rows(x2d, nfft):
     return out
 
 
+# ------------------------------------------------------------------------------------------ A5 (nT-model)
+def frame_sum(y2d, nfft, hop, nframes, detrend=True):
+    """c[ch][n] = sum_g detrended(y[ch][g*hop + n]), n < nfft, for each row of [nch, nsig]; complex128 (float64 for real
+    input) [nch, nfft].  sum_g FFT(win*frame_g) = FFT(win*c): the mean spectrum without writing the frames' spectra."""
+    want, _ = _detrend_args(detrend, None)
+    if want not in (_ffi.DETREND_CONST, _ffi.DETREND_MEAN, _ffi.DETREND_LINEAR):
+        raise ValueError("frame_sum: detrend must be none, mean or linear")
+    if _is_torch(y2d):
+        _bind_stream(y2d)
+        ys = y2d.contiguous()
+        ys = ys.to(torch.complex64) if ys.is_complex() else ys.to(torch.float32)
+        nch, nsig = ys.shape
+        out = torch.empty((nch, int(nfft), 2), dtype=torch.float64, device=ys.device)
+        check(lib().sp_frame_sum(ptr(ys.data_ptr()), _tcode(ys), nsig, nch, nsig, int(nfft), int(hop), int(nframes), want,
+                                 ptr(out.data_ptr()), 1))
+        return torch.view_as_complex(out) if ys.is_complex() else out[..., 0]
+    a = np.asarray(y2d)
+    ys = np.ascontiguousarray(a, dtype=np.complex64 if np.iscomplexobj(a) else np.float32)
+    nch, nsig = ys.shape
+    out = np.empty((nch, int(nfft), 2), dtype=np.float64)
+    _ffi.init()
+    check(lib().sp_frame_sum(ptr(ys), _ffi.dtype_code(ys.dtype), nsig, nch, nsig, int(nfft), int(hop), int(nframes), want,
+                             ptr(out), 0))
+    return out.view(np.complex128)[..., 0] if np.iscomplexobj(ys) else out[..., 0].copy()
+
+
 # ------------------------------------------------------------------------------------------ N4
 def spectral_filter_rows(x2d, H):
     """IFFT(H * FFT(row)) for each real row of [batch, n]; H complex [n] (host table).  complex64 [batch, n]."""

@@ -6,8 +6,7 @@ the correlation epilogue -- runs on the MI355X through libspectral.so in float32
 window tables and the O(nfft) epilogue algebra stay on the host in float64, as in the reference.
 
 Deliberately not carried over (outside the hot-path scope): plotting (`plotit` is accepted
-and ignored), the matplotlib.mlab branch (`useMLAB=True` raises), the nT-model branch (sigx shorter than sigy),
-Monte-Carlo uncertainty helpers, integratespectra/getNpeaks.
+and ignored), Monte-Carlo uncertainty helpers, integratespectra/getNpeaks.
 """
 import numpy as np
 
@@ -152,12 +151,22 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
     if np.shape(sigy)[1] == len(tvec):
         sigy = sigy.T
     nch = np.size(sigy, axis=1)
-    if np.size(sigx, axis=0) != np.size(sigy, axis=0):
-        raise NotImplementedError("sigx and sigy of different length (nT-model branch, fft_analysis.py:170-176)")
-
-    if "minFreq" in kwargs:                                           # :180-190
-        kwargs["tper"] = 2.0 / kwargs["minFreq"]
-    if "tper" in kwargs:
+    nTmodel = np.size(sigx, axis=0) != np.size(sigy, axis=0)          # :169-176 sigx is ONE window long: a model signal
+    if nTmodel:                                                       #          correlated with every window of sigy
+        if not calcNavr:
+            # the reference only defines calcNavr when Navr is None (:120-131) and fails here (:172) otherwise
+            raise UnboundLocalError("local variable 'calcNavr' referenced before assignment (reference behaviour: the "
+                                    "nT-model branch of fft_pwelch takes Navr=None only, fft_analysis.py:172)")
+        nwins = np.size(sigx, axis=0)
+        if i0 == 0 and i1 == len(tvec):
+            # the reference reflects the one-window model as well (:202) and then fails at win*xtemp (:374)
+            raise ValueError("operands could not be broadcast together: the nT-model branch needs tbounds inside the "
+                             "record (no end-point reflection), as in the reference (fft_analysis.py:197-205, :374)")
+        if useMLAB:
+            raise NotImplementedError("nT-model with useMLAB=True (periodic wrapping of the model, fft_analysis.py:268-281)")
+    elif "minFreq" in kwargs or "tper" in kwargs:                     # :180-190
+        if "minFreq" in kwargs:
+            kwargs["tper"] = 2.0 / kwargs["minFreq"]
         nwins = int(Fs * kwargs["tper"])
     else:
         if Navr is None:
@@ -175,6 +184,8 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
     if calcNavr:
         Navr = _navr(nsig, nwins, noverlap)
     if nwins >= nsig:
+        if nTmodel:
+            raise ValueError("nT-model: the model signal must be shorter than the analysed record (fft_analysis.py:215-217, :374)")
         Navr = 1
         nwins = nsig
     nfft = nwins
@@ -189,7 +200,7 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
     info.S1, info.S2, info.NENBW, info.ENBW = _norms(win, Nnyquist, Fs)
 
     # ---- device: detrend + window + FFT + products + segment mean  (fft_analysis.py:339-446)
-    x_in = sigx[i0:i1]
+    x_in = sigx if nTmodel else sigx[i0:i1]                           # :346-354
     y_in = np.ascontiguousarray(sigy[i0:i1, :].T)                    # channel-major for coalesced frame loads
     hop = nwins - noverlap
     scale = 1.0 / (info.S1 ** 2) / info.ENBW                          # :432-440
@@ -218,6 +229,30 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
         Pyy = cut(np.asarray(pyy)).T.astype(np.float64)                # the reference allocates Pyy as float64 (:294)
         Pxy = np.ascontiguousarray(cut(np.asarray(pxy)).T)
         want_segments = False                                             # mlab returns no per-segment arrays
+    elif nTmodel:
+        # every segment pairs the SAME windowed model spectrum X with the segment's Y_g (:366-393):
+        #   Pxx = |X|^2, Pyy = mean_g |Y_g|^2 (fused Welch PSD per channel), Pxy = mean_g(Y_g) conj(X), and
+        #   sum_g Y_g = FFT(win * sum_g y_g) by linearity -- the frames are summed in the time domain on the device
+        #   (sp_frame_sum), one length-nfft transform per channel follows.
+        Xm = _E.stft_frames(x_in, win, nfft, 1, detrend=dflag, sided=_E.SIDED_RAW, amp_scale=1.0)[0][0].astype(np.complex128)
+        csum = _E.frame_sum(y_in, nfft, hop, Navr, detrend=dflag)
+        Ybar = np.atleast_2d(_E.fft((np.asarray(win) * csum).astype(np.complex64))).astype(np.complex128) / Navr
+
+        def cut_raw(P):
+            if onesided:
+                P = P[..., :Nnyquist].copy()
+                P[..., 1:-1] *= 2
+                if nfft % 2:
+                    P[..., -1] *= 2
+                return P
+            return np.fft.fftshift(P, axes=-1)
+        pxx = cut_raw((Xm * np.conj(Xm)).real * scale)
+        pxy = cut_raw(Ybar * np.conj(Xm)[None, :] * scale)
+        pyy = np.stack([_E.welch_psd(y_in[c], win, hop, Navr, detrend=dflag, sided=sided, scale=scale) for c in range(nch)])
+        freq = freq[:Nnyquist] if onesided else np.fft.fftshift(freq)
+        Pxx = pxx.astype(np.complex128)
+        Pyy = pyy.T.astype(np.complex128)
+        Pxy = np.ascontiguousarray(pxy.T)
     else:
         pxx, pyy, pxy = _E.welch_csd(x_in, y_in, win, hop, Navr, detrend=dflag, sided=sided, scale=scale)
         freq = freq[:Nnyquist] if onesided else np.fft.fftshift(freq)
@@ -227,7 +262,10 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
 
     if want_segments:
         amp = 1.0
-        Xs, _ = _E.stft_frames(x_in, win, hop, Navr, detrend=dflag, sided=_E.SIDED_RAW, amp_scale=amp)
+        if nTmodel:
+            Xs = np.repeat(_E.stft_frames(x_in, win, nfft, 1, detrend=dflag, sided=_E.SIDED_RAW, amp_scale=amp)[0], Navr, axis=0)
+        else:
+            Xs, _ = _E.stft_frames(x_in, win, hop, Navr, detrend=dflag, sided=_E.SIDED_RAW, amp_scale=amp)
         Ys = np.stack([_E.stft_frames(y_in[c], win, hop, Navr, detrend=dflag, sided=_E.SIDED_RAW,
                                       amp_scale=amp)[0] for c in range(nch)])
         info.Xfft_seg = Xs.astype(np.complex128)

@@ -503,3 +503,69 @@ def test_spectral_filter_rows_vs_numpy(P):
     h[0] = h[1024] = 1.0
     h[1:1024] = 2.0
     np.testing.assert_allclose(P.engine.spectral_filter_rows(x, h), P.engine.hilbert_rows(x, 2048), rtol=0, atol=1e-6)
+
+
+# ---- A5: the nT-model branch of fft_pwelch (fft_analysis.py:169-176, :346-393) ---------------------------------------
+NT_CASES = {"one_mean": dict(detrend_style=1), "one_linear_hamming": dict(detrend_style=-1, windowfunction="hamming"),
+            "two_none": dict(detrend_style=0, onesided=False)}
+
+
+@pytest.mark.parametrize("tag", sorted(NT_CASES))
+def test_fft_pwelch_ntmodel_golden(P, tag):
+    """a one-window model signal against every window of sigy: Pxy = mean_g(Y_g) conj(X) through the time-domain frame sum
+    (sp_frame_sum), vs what the reference returned for the same inputs (tests/golden/make_golden_ntmodel.py)"""
+    from golden.make_golden_ntmodel import inputs
+    g = load_golden("pwelch_ntmodel")
+    fs, t, xm, y = inputs()
+    tb = list(g["tb"])
+    for ych, ytag in ((y[:, 0], "1ch"), (y, "2ch")):
+        r = P.fft_pwelch(t, xm, ych, tb, **NT_CASES[tag])
+        p = "%s_%s_" % (tag, ytag)
+        np.testing.assert_allclose(r[0], g[p + "freq"], rtol=1e-12, atol=1e-9)
+        for nm, v in zip(("Pxy", "Pxx", "Pyy"), r[1:4]):
+            close_rel(np.asarray(v).reshape(g[p + nm].shape), g[p + nm], 2e-5, p + nm)
+        info = r[6]
+        assert (info.Navr, info.nwins, info.noverlap) == (int(g[p + "Navr"]), int(g[p + "nwins"]), int(g[p + "noverlap"]))
+        for k in ("Lxy", "Rxy", "corrcoef"):          # same bound as test_fft_pwelch_golden (sqrt / normalisation of small bins)
+            close_rel(np.asarray(getattr(info, k)).reshape(g[p + k].shape), g[p + k], 2e-3, p + k)
+        # coherence where the model has power (elsewhere it is a ratio of rounding noise)
+        strong = np.abs(g[p + "Pxx"]) > 1e-6 * np.abs(g[p + "Pxx"]).max()
+        c_ref = g[p + "Cxy"]
+        c_got = np.asarray(r[4]).reshape(c_ref.shape)
+        assert np.max(np.abs(c_got[strong] - c_ref[strong])) <= 1e-3
+    with pytest.raises(UnboundLocalError):
+        P.fft_pwelch(t, xm, y[:, 0], tb, Navr=37)                # the reference's behaviour, recorded in the fixture
+    with pytest.raises(ValueError):
+        P.fft_pwelch(t, xm, y[:, 0], None)
+    # per-segment arrays: the model spectrum repeated
+    r = P.fft_pwelch(t, xm, y, tb, segments=True, **NT_CASES[tag])
+    assert r[6].Xfft_seg.shape == (int(g["%s_2ch_Navr" % tag]), 1024) and np.array_equal(r[6].Xfft_seg[0], r[6].Xfft_seg[-1])
+
+
+def test_frame_sum_vs_numpy(P):
+    """sp_frame_sum: time-domain sum of all frames per channel, with none / mean / linear detrend, real and complex,
+    ragged hop, device tensors; and the linearity it exists for: FFT(win * c) = sum_g FFT(win * frame_g)."""
+    import torch
+    import scipy.signal
+    rng = np.random.default_rng(9)
+    for nch, nsig, nfft, hop, cplx in ((1, 5000, 256, 128, False), (3, 20011, 1000, 333, False), (2, 9000, 512, 512, True),
+                                        (5, 1 << 18, 4096, 1024, False)):
+        y = rng.standard_normal((nch, nsig)) + 0.3 + 1e-4 * np.arange(nsig)
+        if cplx:
+            y = y + 1j * (rng.standard_normal((nch, nsig)) - 0.2)
+        y = y.astype(np.complex64 if cplx else np.float32)
+        M = (nsig - nfft) // hop + 1
+        idx = (np.arange(M) * hop)[:, None] + np.arange(nfft)[None, :]
+        for det in (False, True, "linear"):
+            y64 = y.astype(np.complex128 if cplx else np.float64)
+            if det is True:
+                y64 = y64 - y64.mean(axis=1, keepdims=True)
+            elif det == "linear":
+                y64 = scipy.signal.detrend(y64.real, axis=1) + (1j * scipy.signal.detrend(y64.imag, axis=1) if cplx else 0)
+            ref = np.stack([y64[c][idx].sum(axis=0) for c in range(nch)])
+            got = P.engine.frame_sum(y, nfft, hop, M, detrend=det)
+            assert got.shape == ref.shape
+            scale = np.max(np.abs(y64)) * np.sqrt(M)
+            assert np.max(np.abs(got - ref)) <= 2e-5 * scale * np.sqrt(M), (nch, nsig, det)
+        got_t = P.engine.frame_sum(torch.from_numpy(y).cuda(), nfft, hop, M, detrend=True)
+        np.testing.assert_allclose(got_t.cpu().numpy(), P.engine.frame_sum(y, nfft, hop, M, detrend=True), rtol=1e-12, atol=1e-9)

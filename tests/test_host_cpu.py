@@ -109,10 +109,16 @@ def test_no_cpu_fallback_without_gpu():
         pyfft_amd.ccf(np.zeros(16), np.ones(16), 1.0)
 
 
-def test_unsupported_branches_raise():
+def test_ntmodel_argument_errors_mirror_reference():
+    """nT-model branch (sigx one window long): the reference only runs it with Navr=None and tbounds inside the record
+    (tests/golden/pwelch_ntmodel.npz "errors"); the same exception types come back before any device work"""
     t = np.arange(100.0)
+    with pytest.raises(ValueError):
+        pyfft_amd.fft_pwelch(t, np.zeros(50), np.zeros(100))       # full record: the model would be reflected too
+    with pytest.raises(UnboundLocalError):
+        pyfft_amd.fft_pwelch(t, np.zeros(50), np.zeros(100), [t[2], t[-2]], Navr=4)
     with pytest.raises(NotImplementedError):
-        pyfft_amd.fft_pwelch(t, np.zeros(50), np.zeros(100))       # nT-model branch
+        pyfft_amd.fft_pwelch(t, np.zeros(50), np.zeros(100), [t[2], t[-2]], useMLAB=True)
 
 
 def test_named_window_catalogue_matches_reference():

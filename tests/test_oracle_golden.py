@@ -314,3 +314,30 @@ def test_fft_deriv_against_reference_fixture():
     yy, xx, _ = cases()["sine_aperiodic"]
     d, _ = O.fft_deriv(yy, xx, detrend=lambda v: v - v.mean())
     np.testing.assert_allclose(d, g["sine_aperiodic_detrend_d"], rtol=0, atol=1e-9 * np.max(np.abs(d)))
+
+
+NT_CASES = {"one_mean": dict(detrend_style=1), "one_linear_hamming": dict(detrend_style=-1, windowfunction="hamming"),
+            "two_none": dict(detrend_style=0, onesided=False)}
+
+
+@pytest.mark.parametrize("tag", sorted(NT_CASES))
+def test_fft_pwelch_ntmodel_branch(tag):
+    """nT-model branch (fft_analysis.py:169-176, :346-393): a one-window model signal against every window of sigy"""
+    from golden.make_golden_ntmodel import inputs
+    g = load_golden("pwelch_ntmodel")
+    fs, t, xm, y = inputs()
+    tb = list(g["tb"])
+    for ych, ytag in ((y[:, 0], "1ch"), (y, "2ch")):
+        r = O.fft_pwelch(t, xm, ych, tb, **NT_CASES[tag])
+        p = "%s_%s_" % (tag, ytag)
+        for nm, v in zip(("freq", "Pxy", "Pxx", "Pyy", "Cxy", "phi_xy"), r[:6]):
+            ref = g[p + nm]
+            np.testing.assert_allclose(np.asarray(v).reshape(ref.shape), ref, rtol=1e-9, atol=1e-12 * np.max(np.abs(ref)), err_msg=p + nm)
+        for k in ("S1", "S2", "ENBW", "NENBW", "Navr", "nwins", "noverlap", "Lxy", "Rxy", "corrcoef", "lags"):
+            ref = g[p + k]
+            np.testing.assert_allclose(np.asarray(r[6][k]).reshape(ref.shape), ref, rtol=1e-8, atol=1e-11 * max(1.0, np.max(np.abs(ref))), err_msg=p + k)
+    assert list(g["errors"]) == ["UnboundLocalError", "ValueError"]
+    with pytest.raises(UnboundLocalError):
+        O.fft_pwelch(t, xm, y[:, 0], tb, Navr=37)
+    with pytest.raises(ValueError):
+        O.fft_pwelch(t, xm, y[:, 0], None)
