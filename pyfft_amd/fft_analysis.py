@@ -348,15 +348,6 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
 
 
 # ------------------------------------------------------------------------------------------
-# fftanal
-# ------------------------------------------------------------------------------------------
-# ------------------------------------------------------------------------------------------------------------------
-# psd / csd / coh / coh2 (fft_analysis.py:1060-1155): the reference's thin wrappers over matplotlib.mlab.psd / csd.
-# mlab's estimator (symmetric Hann = mlab.window_hanning, step NFFT - noverlap, detrend PER SEGMENT, conj(X) Y / Fs /
-# sum(w^2), one-sided doubling except DC and Nyquist, mean over segments) runs on the device through welch_psd /
-# welch_csd; only the band selection stays on the host.  Real input (the reference's use).
-# ------------------------------------------------------------------------------------------------------------------
-# ------------------------------------------------------------------------------------------
 # detrend handles (reference: pybaseutils.utils.detrend_*, imported at fft_analysis.py:23 and re-exported by the
 # package; that source is absent, the semantics -- along axis 0, like matplotlib.mlab.detrend_* -- are SURVEY 8c's
 # stated assumption) and the derivative by FFT (fft_analysis.py:1399-1587)
@@ -466,6 +457,12 @@ def fft_deriv(sig, xx=None, lowpass=True, Fs_new=None, modified=True, detrend=de
     return d, xx
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# psd / csd / coh / coh2 (fft_analysis.py:1060-1155): the reference's thin wrappers over matplotlib.mlab.psd / csd.
+# mlab's estimator (symmetric Hann = mlab.window_hanning, step NFFT - noverlap, detrend PER SEGMENT, conj(X) Y / Fs /
+# sum(w^2), one-sided doubling except DC and Nyquist, mean over segments) runs on the device through welch_psd /
+# welch_csd; only the band selection stays on the host.  Real input (the reference's use).
+# ------------------------------------------------------------------------------------------------------------------
 def _mlab_detrend_code(detrend):
     if detrend in (None, "none", False):
         return False
@@ -546,6 +543,9 @@ def coh2(x, y, fs, nfft=4096, fmin=0, fmax=500e3, detrend='none', peak_treshold=
             'pha': np.arctan2(Pxy.imag, Pxy.real)[keep]}
 
 
+# ------------------------------------------------------------------------------------------
+# fftanal
+# ------------------------------------------------------------------------------------------
 class fftanal(Struct):
     """Welch / STFT analysis object (reference: fft_analysis.py:1695-2048).
 
