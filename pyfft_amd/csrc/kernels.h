@@ -2282,17 +2282,58 @@ __global__ __launch_bounds__(256) void k_moments_partial(const void *__restrict_
                                                           double *__restrict__ partial, int64_t x_cs) {
     double s[SP_MOM] = {0, 0, 0, 0, 0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t off = (int64_t)blockIdx.y * x_cs;
     partial += (int64_t)blockIdx.y * gridDim.x * 8;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const cf a = load_sample(x, off + i, CPLX);
-        s[0] += a.x;
-        s[1] += a.y;
-        s[2] += (double)a.x * a.x + (double)a.y * a.y;
+    auto acc = [&](float re, float im, int64_t i) {
+        s[0] += re;
+        s[1] += im;
+        s[2] += (double)re * re + (double)im * im;
         if constexpr (LIN) {
             const double di = (double)i;
-            s[3] += di * a.x;
-            s[4] += di * a.y;
+            s[3] += di * re;
+            s[4] += di * im;
+        }
+    };
+    // 16-byte loads, four in flight per thread (one dword per thread and iteration kept ~8 KB per CU in flight: 3.1 TB/s);
+    // the few samples before the first 16-byte boundary and after the last whole vector go through scalar loads
+    constexpr int VEC = CPLX ? 2 : 4;
+    constexpr int ESZ = CPLX ? 8 : 4;
+    const char *base = reinterpret_cast<const char *>(x) + off * ESZ;
+    int64_t head = (int64_t)(((16 - (reinterpret_cast<uintptr_t>(base) & 15)) & 15) / ESZ);
+    if (head > n) head = n;
+    const int64_t nvec = (n - head) / VEC;
+    const float4 *xv = reinterpret_cast<const float4 *>(base + head * ESZ);
+    auto accv = [&](const float4 &q, int64_t j) {
+        const int64_t i = head + j * VEC;
+        if constexpr (CPLX) {
+            acc(q.x, q.y, i);
+            acc(q.z, q.w, i + 1);
+        } else {
+            acc(q.x, 0.f, i);
+            acc(q.y, 0.f, i + 1);
+            acc(q.z, 0.f, i + 2);
+            acc(q.w, 0.f, i + 3);
+        }
+    };
+    int64_t j = gtid;
+    for (; j + 3 * stride < nvec; j += 4 * stride) {
+        const float4 q0 = xv[j], q1 = xv[j + stride], q2 = xv[j + 2 * stride], q3 = xv[j + 3 * stride];
+        accv(q0, j);
+        accv(q1, j + stride);
+        accv(q2, j + 2 * stride);
+        accv(q3, j + 3 * stride);
+    }
+    for (; j < nvec; j += stride) accv(xv[j], j);
+    if (blockIdx.x == 0) {
+        const int64_t tail0 = head + nvec * VEC;
+        if ((int64_t)threadIdx.x < head) {
+            const cf a = load_sample(x, off + threadIdx.x, CPLX);
+            acc(a.x, a.y, threadIdx.x);
+        }
+        if (tail0 + (int64_t)threadIdx.x < n) {
+            const cf a = load_sample(x, off + tail0 + threadIdx.x, CPLX);
+            acc(a.x, a.y, tail0 + threadIdx.x);
         }
     }
     __shared__ double sh[SP_MOM][256];
