@@ -4,7 +4,7 @@ namespace sp {
 
 int launch_stft(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
                 bool lin, const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg,
-                int segmean, double *cog, int klo, int khi) {
+                int segmean, cf *cog, int klo, int khi) {
 #define L_(XT, CP, LN)                                                                                \
     hipLaunchKernelGGL((k_stft<XT, CP, LN>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, win, hop, \
                        nframes, rp.fpg, trend, xf.tb, sided, amp, out_power, out, pseg, segmean, cog, klo, khi)
@@ -43,8 +43,8 @@ int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64
     return 0;
 }
 
-int launch_cog_finish(LaunchCtx c, const double *acc, int64_t nframes, double df, double *out) {
-    hipLaunchKernelGGL(k_cog_finish, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, c.stream, acc, nframes, df, out);
+int launch_cog_finish(LaunchCtx c, const cf *acc, int wpf, int64_t nframes, double df, double *out) {
+    hipLaunchKernelGGL(k_cog_finish, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, c.stream, acc, wpf, nframes, df, out);
     return 0;
 }
 

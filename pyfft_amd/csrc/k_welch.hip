@@ -41,6 +41,44 @@ static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int
 #undef CARRY_
 }
 
+// centre-of-gravity moments per frame on the carry kernel (power-of-two nfft, hop = nfft/4, /2 or nfft; constant detrend;
+// every bin)
+template <int N, bool CPLX>
+static bool try_carry_cog(LaunchCtx c, const void *x, const float *win, int hop, int64_t nframes, const float *trend,
+                          const Xf &xf, cf *cog, const RunPart &rp) {
+    using C = WgCfg<N>;
+    const int shift = hop / C::T;
+#define COG_(S)                                                                                       \
+    case S:                                                                                           \
+        hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF), \
+                           c.stream, x, win, nframes, rp.fpg, trend, xf.tb, reinterpret_cast<float *>(cog), (cf *)nullptr); \
+        return true;
+    switch (shift) {
+        COG_(4) COG_(8) COG_(16)
+        default: return false;
+    }
+#undef COG_
+}
+
+// returns 1 when the shape is not eligible (the caller falls back to the generic frame kernel)
+int launch_cog_carry(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
+                     const Xf &xf, cf *cog, const RunPart &rp, int klo, int khi) {
+    if (!welch_carry_eligible(xf, hop, false)) return 1;
+    if (klo > 0 || khi < xf.L / 2) return 1;          // the streaming kernel weighs every bin; a band goes the generic way
+    bool done = false;
+#define TRY_(NN)                                                                                      \
+    case NN:                                                                                          \
+        done = cplx ? try_carry_cog<NN, true>(c, x, win, hop, nframes, trend, xf, cog, rp)  \
+                    : try_carry_cog<NN, false>(c, x, win, hop, nframes, trend, xf, cog, rp); \
+        break;
+    switch (xf.L) {
+        TRY_(256) TRY_(512) TRY_(1024) TRY_(2048) TRY_(4096) TRY_(8192)
+        default: break;
+    }
+#undef TRY_
+    return done ? 0 : 1;
+}
+
 int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
                  bool lin, const Xf &xf, float *partial, const RunPart &rp, bool allow_carry, cf *spartial,
                  const char **kname, int segmean) {

@@ -102,6 +102,22 @@ __device__ __forceinline__ cf load_sample(const void *x, int64_t i, bool cplx) {
     return mk(reinterpret_cast<const float *>(x)[i], 0.f);
 }
 
+// sum over the 64 lanes of a wave without the LDS pipe: xor-butterfly inside each row of 16 lanes with DPP (quad_perm
+// [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror -- after each step the partner groups hold equal values, so the mirrors
+// act as xor 4 / xor 8), then the four row sums through v_readlane.  The result is uniform.
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum64(float v) {
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    v = dpp_add<0x140>(v);
+    const int b = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(b, 0)) + __int_as_float(__builtin_amdgcn_readlane(b, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
+}
+
 // detrend parameters of one signal: value removed at global sample index i is  m + s*i
 struct Trend {
     cf m, s;
@@ -469,13 +485,18 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_rp(const float *__restrict__
 #endif
 // (no min-waves hint: capping at 168 VGPRs makes hipcc spill the window registers and reload them inside the
 //  frame loop behind vmcnt(0) waits, which also drains the prefetch loads -- measured 2x slower)
-template <int N, bool CPLX, int SHIFT, bool ONEPASS>
+// COG: instead of accumulating |X|^2 over the frames, every frame's spectral moments sum ks|X|^2, sum |X|^2 (signed bin
+// index ks, every bin) are reduced across the wave and stored in the slot (frame, wave) of a float2 array
+// (`partial` carries that pointer; k_cog_finish adds the slots) -- the centre of gravity per frame of Doppler.cog / cogspec (Doppler.py:43-81)
+// on the streaming path of the metric kernel.
+template <int N, bool CPLX, int SHIFT, bool ONEPASS, bool COG = false>
 __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
     const void *__restrict__ x, const float *__restrict__ win, int64_t nframes, int64_t fpg,
     const float *__restrict__ trend, XfTables tb, float *__restrict__ partial, cf *__restrict__ spartial) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
+    static_assert(!(COG && ONEPASS), "the moments mode has no one-pass detrend epilogue");
     static_assert(SHIFT >= 1 && SHIFT <= C::R, "hop must be 1..R register slots");
     constexpr int KEEP = C::R - SHIFT;
     constexpr bool UNI = C::FPW == 1;          // one group per workgroup: trip counts may differ between groups
@@ -531,6 +552,19 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
             }
         }
     };
+    // COG: a wave keeps the moments of its last W frames spread over its lanes (frame i in lane i mod W) and writes them
+    // with one coalesced store every W frames.  A store per frame costs 0.27 ms at the metric shape although it is 8 bytes
+    // per wave: gfx9 counts loads and stores in one vmcnt, the wait for the prefetched samples is vmcnt(0), and a partial-line
+    // store takes longer to be acknowledged than the loads issued with it -- every frame waited for it (measured with a
+    // no-store build: 0.61 vs 0.88 ms; issuing the store a frame earlier did not help).  A float64 atomicAdd is worse still
+    // (compare-and-swap loop).  Layout acc[wave of the frame][frame], summed over the waves by k_cog_finish.
+    cf pend = mk(0.f, 0.f);
+    auto flush = [&](int64_t i) __attribute__((always_inline)) {
+        constexpr int W = C::T < 64 ? C::T : 64;
+        const int sel = (int)(i & (W - 1)), li = tid & (W - 1);
+        const int64_t gg = g0 + (i - sel) + li;
+        if (li <= sel && gg < nframes) reinterpret_cast<cf *>(partial)[(int64_t)(tid / W) * nframes + gg] = pend;
+    };
     // one frame: window, transform, accumulate; `fill` receives a prefetch (issued once v is formed, so that the
     // incoming samples can take over the registers of the slots that just died), `take` holds the new slots of frame g+1
     auto body = [&](int64_t i, cf (&fill)[SHIFT], int64_t fill_frame, cf (&take)[SHIFT]) __attribute__((always_inline)) {
@@ -552,11 +586,37 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
         } else {
             xf.fwd(v, lds, tid, N);
         }
+        if constexpr (COG) {
+            // every bin (Doppler.cog's form; a band limit goes through the generic kernel): with ks = tid + c_t,
+            // c_t = T t - (N in the upper half), sum ks p = tid * sum p + sum c_t p -- one FMA with a literal per bin
+            float numc = 0.f, den = 0.f;
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) {
-            // two chained FMAs per bin (`acc + (x*x + y*y)` would be mul + fma + add)
-            if (UNI) acc[t] = fmaf(v[t].y, v[t].y, fmaf(v[t].x, v[t].x, acc[t]));
-            else acc[t] += keep * cnorm(v[t]);
+            for (int t = 0; t < C::R; ++t) {
+                const float p = cnorm(v[t]);
+                numc = fmaf(p, (float)(C::T * t - (t >= C::R / 2 ? N : 0)), numc);
+                den += p;
+            }
+            float num = fmaf((float)tid, den, numc);
+            constexpr int W = C::T < 64 ? C::T : 64;
+            if constexpr (W == 64) {
+                num = wave_sum64(num);
+                den = wave_sum64(den);
+            } else {
+#pragma unroll
+                for (int o = W / 2; o > 0; o >>= 1) {
+                    num += __shfl_xor(num, o);
+                    den += __shfl_xor(den, o);
+                }
+            }
+            if ((tid & (W - 1)) == (int)(i & (W - 1))) pend = mk(num, den);
+            if ((i & (W - 1)) == W - 1 || i == trips - 1) flush(i);
+        } else {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                // two chained FMAs per bin (`acc + (x*x + y*y)` would be mul + fma + add)
+                if (UNI) acc[t] = fmaf(v[t].y, v[t].y, fmaf(v[t].x, v[t].x, acc[t]));
+                else acc[t] += keep * cnorm(v[t]);
+            }
         }
         // advance one hop: rename registers, detrend the samples that arrived
 #pragma unroll
@@ -570,8 +630,10 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
         cf nx[SHIFT];
         body(i, nx, g0 + i + 1, nx);
     }
+    if constexpr (!COG) {
 #pragma unroll
-    for (int t = 0; t < C::R; ++t) partial[gid * N + tid + C::T * t] = acc[t];
+        for (int t = 0; t < C::R; ++t) partial[gid * N + tid + C::T * t] = acc[t];
+    }
     if (ONEPASS) {
 #pragma unroll
         for (int s = 0; s < SHIFT; ++s) spartial[gid * hop + tid + C::T * s] = sacc[s];
@@ -1350,7 +1412,7 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
                                                     int64_t nframes, int64_t fpg, const float *__restrict__ trend,
                                                     XfTables tb, int sided, float amp, int out_power,
                                                     void *__restrict__ out, double *__restrict__ pseg, int segmean,
-                                                    double *__restrict__ cog, int klo, int khi) {
+                                                    cf *__restrict__ cog, int klo, int khi) {
     SP_KERNEL_PROLOGUE(X)
     float w[C::R];
 #pragma unroll
@@ -1403,8 +1465,7 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
                 den += __shfl_xor(den, o);
             }
             if ((tid & (W - 1)) == 0 && act) {
-                atomicAdd(&cog[2 * g], (double)num);
-                atomicAdd(&cog[2 * g + 1], (double)den);
+                cog[(int64_t)(tid / W) * nframes + g] = mk(num, den);   // slot [wave of the frame][frame], summed by k_cog_finish
             }
             continue;
         }
@@ -1426,11 +1487,16 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
     }
 }
 
-// cog[g] = df * num / den (0 where the band holds no power), in place over the moment pairs' first half
-static __global__ void k_cog_finish(const double *__restrict__ acc, int64_t nframes, double df, double *__restrict__ out) {
+// cog[g] = df * num / den (0 where the band holds no power) from the per-wave moment slots acc[wpf][g] = (num, den)
+static __global__ void k_cog_finish(const cf *__restrict__ acc, int wpf, int64_t nframes, double df, double *__restrict__ out) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nframes) return;
-    const double num = acc[2 * g], den = acc[2 * g + 1];
+    double num = 0.0, den = 0.0;
+    for (int w = 0; w < wpf; ++w) {
+        const cf a = acc[(int64_t)w * nframes + g];
+        num += (double)a.x;
+        den += (double)a.y;
+    }
     out[g] = den > 0.0 ? df * num / den : 0.0;
 }
 

@@ -125,8 +125,10 @@ int launch_csd_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf
                       double *pxx, double *pyy, double *pxy);
 int launch_stft(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
                 bool lin, const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg, int segmean = 0,
-                double *cog = nullptr, int klo = 0, int khi = 0);
-int launch_cog_finish(LaunchCtx c, const double *acc, int64_t nframes, double df, double *out);
+                cf *cog = nullptr, int klo = 0, int khi = 0);
+int launch_cog_finish(LaunchCtx c, const cf *acc, int wpf, int64_t nframes, double df, double *out);
+int launch_cog_carry(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,
+                     const Xf &xf, cf *cog, const RunPart &rp, int klo, int khi);
 bool csd_rp_eligible(const Xf &xf);
 int launch_csd_rp(LaunchCtx c, const float *x, const float *y, int nch, int64_t y_ld, const float *win, int hop,
                   int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,

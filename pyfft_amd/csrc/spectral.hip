@@ -1269,19 +1269,26 @@ int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int 
     const int klo = (int)std::ceil(fmin / df - eps);
     const double kh = std::floor(fmax / df + eps);
     const int khi = kh > (double)nfft ? nfft : (int)kh;
-    const size_t abytes = sizeof(double) * 2 * (size_t)nframes;
+    const int wpf = xf.L / 16 >= 64 ? xf.L / 16 / 64 : 1;           // waves per frame: one (num, den) slot each
+    const size_t abytes = sizeof(cf) * (size_t)wpf * (size_t)nframes;
     if (g.work.ensure(abytes)) return -1;
-    double *acc = (double *)g.work.p;
+    cf *acc = (cf *)g.work.p;
     double *fin = cog_out;
     if (!mem) {
         if (g.out0.ensure(sizeof(double) * (size_t)nframes)) return -1;
         fin = (double *)g.out0.p;
     }
-    HIPCHK(hipMemsetAsync(acc, 0, abytes, g.stream));
     const RunPart rp = run_partition(xf.L, nframes, g.ncu);
-    LAUNCHCHK(launch_stft(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, 2, 1.f, 1, nullptr,
-                          nullptr, segmean, acc, klo, khi));
-    LAUNCHCHK(launch_cog_finish(lc(), acc, nframes, df, fin));
+    // streaming form (every sample read once, the overlap carried in registers) when the shape allows; SP_COG_GENERIC=1
+    // forces the generic frame kernel (A/B test)
+    int generic = 1;
+    if (!segmean && detrend != 2 && !env_flag("SP_COG_GENERIC"))
+        generic = launch_cog_carry(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, acc, rp, klo, khi);
+    if (generic < 0) return fail("sp_stft_cog: launch failed");
+    if (generic)
+        LAUNCHCHK(launch_stft(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, 2, 1.f, 1, nullptr,
+                              nullptr, segmean, acc, klo, khi));
+    LAUNCHCHK(launch_cog_finish(lc(), acc, wpf, nframes, df, fin));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(cog_out, fin, sizeof(double) * (size_t)nframes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));

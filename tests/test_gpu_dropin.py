@@ -569,3 +569,23 @@ def test_frame_sum_vs_numpy(P):
             assert np.max(np.abs(got - ref)) <= 2e-5 * scale * np.sqrt(M), (nch, nsig, det)
         got_t = P.engine.frame_sum(torch.from_numpy(y).cuda(), nfft, hop, M, detrend=True)
         np.testing.assert_allclose(got_t.cpu().numpy(), P.engine.frame_sum(y, nfft, hop, M, detrend=True), rtol=1e-12, atol=1e-9)
+
+
+def test_doppler_cog_streaming_and_generic_paths_agree(P, monkeypatch):
+    """sp_stft_cog has two forms: the register-carried streaming kernel (power-of-two window, hop = win/4, /2 or win) and the
+    generic frame kernel (everything else; SP_COG_GENERIC=1 forces it).  Same moments, float32 rounding apart."""
+    g = load_golden("doppler_cog")
+    fs, z, r = float(g["fs"]), g["z"], g["r"]
+    t = np.arange(len(z)) / fs
+    for x in (z, r):
+        for win, ov in ((256, 0.5), (512, 0.75), (1024, 0.0), (4096, 0.5)):
+            for kw in (dict(), dict(fmin=40e3, fmax=260e3), dict(detrend=True)):
+                monkeypatch.delenv("SP_COG_GENERIC", raising=False)
+                _, a = P.cog_frames(t, x, fs, win=win, ov=ov, **kw)
+                monkeypatch.setenv("SP_COG_GENERIC", "1")
+                _, b = P.cog_frames(t, x, fs, win=win, ov=ov, **kw)
+                monkeypatch.delenv("SP_COG_GENERIC", raising=False)
+                np.testing.assert_allclose(a, b, rtol=0, atol=2e-6 * fs, err_msg="%d %.2f %s" % (win, ov, sorted(kw)))
+                _, ref = O.cog_frames(t, x - (x.mean() if kw.get("detrend") else 0), fs, win=win, ov=ov,
+                                      **{k: v for k, v in kw.items() if k != "detrend"})
+                np.testing.assert_allclose(a, ref, rtol=0, atol=3e-6 * fs)
