@@ -553,11 +553,9 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry(
         }
     };
     // COG: a wave keeps the moments of its last W frames spread over its lanes (frame i in lane i mod W) and writes them
-    // with one coalesced store every W frames.  A store per frame costs 0.27 ms at the metric shape although it is 8 bytes
-    // per wave: gfx9 counts loads and stores in one vmcnt, the wait for the prefetched samples is vmcnt(0), and a partial-line
-    // store takes longer to be acknowledged than the loads issued with it -- every frame waited for it (measured with a
-    // no-store build: 0.61 vs 0.88 ms; issuing the store a frame earlier did not help).  A float64 atomicAdd is worse still
-    // (compare-and-swap loop).  Layout acc[wave of the frame][frame], summed over the waves by k_cog_finish.
+    // with one coalesced store every W frames, layout acc[wave of the frame][frame], summed over the waves by k_cog_finish.
+    // (First form: two float64 atomicAdd per wave and frame after __shfl_xor sums -- 0.86 ms kernel at the metric shape;
+    //  per-wave slots with plain stores, DPP sums and the literal-FMA moments below: 0.71-0.79 ms.)
     cf pend = mk(0.f, 0.f);
     auto flush = [&](int64_t i) __attribute__((always_inline)) {
         constexpr int W = C::T < 64 ? C::T : 64;
