@@ -118,6 +118,17 @@ __device__ __forceinline__ float wave_sum64(float v) {
            (__int_as_float(__builtin_amdgcn_readlane(b, 32)) + __int_as_float(__builtin_amdgcn_readlane(b, 48)));
 }
 
+// sum over the lanes of one frame group inside a wave (W = min(T, 64) lanes, a power of two); every lane gets the sum
+template <int W> __device__ __forceinline__ float group_lane_sum(float v) {
+    if constexpr (W == 64) {
+        return wave_sum64(v);
+    } else {
+#pragma unroll
+        for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        return v;
+    }
+}
+
 // detrend parameters of one signal: value removed at global sample index i is  m + s*i
 struct Trend {
     cf m, s;
@@ -1440,7 +1451,11 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
             v[t] = w[t] * detrended<LIN>(v[t], tr, base + j);
             pw += ((j == 0 || j == n - 1) ? 0.5f : 1.f) * cnorm(v[t]);
         }
-        if (pseg != nullptr && act) atomicAdd(&pseg[g], (double)pw);
+        if (pseg != nullptr) {        // one atomic per wave and frame instead of one per thread
+            constexpr int W = C::T < 64 ? C::T : 64;
+            pw = group_lane_sum<W>(pw);
+            if (act && (tid & (W - 1)) == 0) atomicAdd(&pseg[g], (double)pw);
+        }
         xf.fwd(v, lds, tid, n);
         if (cog != nullptr) {
             // centre of gravity of the frame's two-sided power spectrum (Doppler.py:43-58): moments sum |X|^2 ks and
@@ -1551,9 +1566,14 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
             pwa += e * v[t].x * v[t].x;
             pwb += e * v[t].y * v[t].y;
         }
-        if (pseg != nullptr && act) {
-            atomicAdd(&pseg[ga], (double)pwa);
-            if (has_b) atomicAdd(&pseg[ga + 1], (double)pwb);
+        if (pseg != nullptr) {        // one atomic per wave and frame instead of one per thread
+            constexpr int W = C::T < 64 ? C::T : 64;
+            pwa = group_lane_sum<W>(pwa);
+            pwb = group_lane_sum<W>(pwb);
+            if (act && (tid & (W - 1)) == 0) {
+                atomicAdd(&pseg[ga], (double)pwa);
+                if (has_b) atomicAdd(&pseg[ga + 1], (double)pwb);
+            }
         }
         xf.fwd(v, lds, tid, N);
         // mirror exchange
