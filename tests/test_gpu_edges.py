@@ -165,3 +165,15 @@ def test_long_hilbert_three_pass_fused_mask(monkeypatch):
         z5 = E.hilbert_rows(u, n)
         monkeypatch.delenv("SP_BIGFFT_5PASS")
         assert np.max(np.abs(z - z5)) <= 2e-5 * np.abs(ref).max()
+
+
+def test_edge_shapes_of_cog_frame_sum_spectral_filter_deriv(P):
+    """tests/edge_probe.py: tiny / odd / Bluestein / multi-wave / long shapes of cog_frames, frame_sum,
+    spectral_filter_rows, fft_deriv and cog against the oracle or numpy (41 cases)"""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("edge_probe", os.path.join(ROOT, "tests", "edge_probe.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run() == []
