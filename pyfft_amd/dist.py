@@ -142,3 +142,33 @@ def welch_csd_channel_sharded(x, y_local, win, hop, nframes, scale=1.0, sided=2,
         cat = torch.cat(parts, dim=0)
         outs.append(cat if isinstance(a, torch.Tensor) else cat.numpy())
     return pxx, outs[0], outs[1]
+
+
+def cog_frames_sharded(x_local, win, plan, fs, fmin=0.0, fmax=None, mean_value=None, gather=True, group=None, backend=None):
+    """Centre of gravity of every frame of one long stream (Doppler.py:43-81), frames dealt out as in `shard_plan`: frames
+    are independent, so the data path has NO collective -- every rank runs `engine.stft_cog` on its frames (plus halo).
+    gather=True additionally all-gathers the per-frame results (8 bytes per frame) so that every rank returns the whole
+    vector [frames_total]; gather=False returns the rank's own [plan.frames].  A global-mean detrend needs the mean of the
+    whole stream: pass it as `mean_value` (e.g. from `welch_psd_sharded_two_step`'s sum all-reduce); default none.
+    `backend(x, win, hop, frames, fs, fmin, fmax, mean_value)` -> float64 [frames]; default: the HIP kernels."""
+    import torch
+    import torch.distributed as dist
+    if backend is None:
+        from . import engine as E
+
+        def backend(x, w, hop, frames, fs_, lo, hi, mv):
+            return E.stft_cog(x, w, hop, frames, fs_, fmin=lo, fmax=hi, detrend=mv is not None, mean_value=mv)
+    mine = backend(x_local, win, plan.hop, plan.frames, fs, fmin, fmax, mean_value)
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world == 1 or not gather:
+        return mine
+    t = mine if isinstance(mine, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(mine, dtype=np.float64))
+    # frame counts differ by at most one between ranks (shard_plan): pad to the largest, gather, trim
+    base, extra = divmod(plan.frames_total, plan.world)
+    width = base + (1 if extra else 0)
+    padded = torch.zeros(width, dtype=torch.float64, device=t.device)
+    padded[:plan.frames] = t
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    out = torch.cat([parts[r][:base + (1 if r < extra else 0)] for r in range(world)])
+    return out if isinstance(mine, torch.Tensor) else out.numpy()

@@ -179,3 +179,53 @@ def test_channel_sharded_csd_gathers_all_channels(tmp_path):
         for c in range(nch):
             np.testing.assert_allclose(d["pyy"][c], g[:, c + 1, c + 1].real, rtol=1e-12)
             np.testing.assert_allclose(d["pxy"][c], g[:, c + 1, 0], rtol=1e-10, atol=1e-12 * np.abs(g).max())
+
+
+def _cog_stream(total):
+    rng = np.random.default_rng(77)
+    k = np.arange(total)
+    f = 0.05 + 0.2 * k / total
+    return np.exp(2j * np.pi * np.cumsum(f)) + 0.2 * (rng.standard_normal(total) + 1j * rng.standard_normal(total))
+
+
+def _cog_backend(x, w, hop, frames, fs, lo, hi, mv):      # oracle in place of the HIP kernels
+    xx = np.asarray(x) - (mv if mv is not None else 0.0)
+    t = np.arange(len(xx)) / fs
+    nfft = len(w)
+    assert (len(xx) - nfft) // hop + 1 >= frames
+    ov = 1.0 - hop / nfft
+    return O.cog_frames(t, xx, fs, win=nfft, ov=ov, fmin=lo if lo else None, fmax=hi, window=w)[1][:frames]
+
+
+def _cog_worker(rank, world, port, total, nfft, hop, out_dir):
+    import torch.distributed as dist
+    from pyfft_amd.dist import shard_plan, cog_frames_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = _cog_stream(total)
+    plan = shard_plan(total, nfft, hop, world, rank)
+    x_local = z[plan.first_sample:plan.first_sample + plan.nsamples]
+    w = O.windows("Hanning", nwins=nfft)
+    full = cog_frames_sharded(x_local, w, plan, 1.0e3, mean_value=z.mean(), backend=_cog_backend)
+    own = cog_frames_sharded(x_local, w, plan, 1.0e3, mean_value=z.mean(), gather=False, backend=_cog_backend)
+    np.savez(os.path.join(out_dir, "g%d.npz" % rank), full=full, own=own, f0=plan.first_frame)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_cog_frames_needs_no_exchange_and_gathers(tmp_path, world):
+    """frames are independent: every rank's own results equal its slice of the single-process vector; gather=True returns
+    the whole vector on every rank (uneven frame counts: 3 ranks over 77 frames)"""
+    total, nfft, hop = 5120, 256, 64
+    port = 35000 + os.getpid() % 2000 + world
+    mp.spawn(_cog_worker, args=(world, port, total, nfft, hop, str(tmp_path)), nprocs=world, join=True)
+    z = _cog_stream(total)
+    M = (total - nfft) // hop + 1
+    ref = _cog_backend(z, O.windows("Hanning", nwins=nfft), hop, M, 1.0e3, 0.0, None, z.mean())
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "g%d.npz" % r))
+        assert d["full"].shape == (M,)
+        np.testing.assert_allclose(d["full"], ref, rtol=1e-9, atol=1e-9)
+        f0 = int(d["f0"])
+        np.testing.assert_allclose(d["own"], ref[f0:f0 + len(d["own"])], rtol=1e-9, atol=1e-9)

@@ -102,3 +102,42 @@ def test_channel_means_and_given_means(tmp_path):
     g0 = E.csd_matrix(x, win, 128, M, detrend=True)
     g1 = E.csd_matrix(x, win, 128, M, means=m)
     assert np.max(np.abs(g0 - g1)) <= 1e-6 * np.abs(g0).max()
+
+
+def _cog_stream(total):
+    rng = np.random.default_rng(78)
+    k = np.arange(total)
+    f = 0.05 + 0.2 * k / total
+    z = np.exp(2j * np.pi * np.cumsum(f)) + 0.2 * (rng.standard_normal(total) + 1j * rng.standard_normal(total))
+    return z.astype(np.complex64)
+
+
+def _cog_worker(rank, world, port, total, nfft, hop, out_dir):
+    import torch
+    import torch.distributed as dist
+    from pyfft_amd.dist import shard_plan, cog_frames_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    z = _cog_stream(total)
+    plan = shard_plan(total, nfft, hop, world, rank)
+    x_local = torch.from_numpy(z[plan.first_sample: plan.first_sample + plan.nsamples]).cuda()
+    c = cog_frames_sharded(x_local, np.ones(nfft), plan, 1.0e3)
+    assert c.is_cuda and c.shape == (plan.frames_total,)
+    np.save(os.path.join(out_dir, "c%d.npy" % rank), c.cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_sharded_cog_frames(tmp_path):
+    """frames dealt out to two ranks, the streaming moments kernel on each shard (+ halo), results all-gathered: every rank
+    holds the single-process vector of the whole stream"""
+    import torch.multiprocessing as mp
+    world, total, nfft, hop = 2, 1024 + 512 * 801, 1024, 512
+    port = 30300 + os.getpid() % 300
+    mp.spawn(_cog_worker, args=(world, port, total, nfft, hop, str(tmp_path)), nprocs=world, join=True)
+    z = _cog_stream(total)
+    _, ref = O.cog_frames(np.arange(total) / 1.0e3, z, 1.0e3, win=nfft, ov=0.5)
+    for r in range(world):
+        c = np.load(os.path.join(str(tmp_path), "c%d.npy" % r))
+        np.testing.assert_allclose(c, ref, rtol=0, atol=3e-6 * 1.0e3)
