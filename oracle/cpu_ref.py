@@ -10,7 +10,7 @@ reference's is (SURVEY.md quirks Q1-Q6 are reproduced, not "fixed").
 
 Pinning: tests/test_oracle_golden.py checks every function here against the
 fixtures in tests/golden/*.npz, which were produced by running the reference's
-own modules (tests/golden/make_golden.py), plus the reference's known-answer
+own modules (tests/golden/make_golden*.py), plus the reference's known-answer
 material (hilbert.py:115-140 analytic identity, notch_filter.py:66-71, Heinzel
 window constants echoed at windows.py:68-269).
 Unpinned boundary: pybaseutils.utils.detrend_* is absent from the reference
