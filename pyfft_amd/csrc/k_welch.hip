@@ -25,14 +25,21 @@ static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int
                       const Xf &xf, float *partial, const RunPart &rp, cf *spartial) {
     using C = WgCfg<N>;
     const int shift = hop / C::T;
+    constexpr bool HINT = N >= 512;       // see k_welch_carry / k_welch_carry_nh
+    const size_t lds = C::lds_bytes(SP_CARRY_NBUF) + carry_lds_pad();
 #define CARRY_(S)                                                                                     \
     case S:                                                                                           \
-        if (spartial)                                                                                 \
-            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + carry_lds_pad(), c.stream, \
-                               x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
-        else                                                                                          \
-            hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF) + carry_lds_pad(), c.stream, \
-                               x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);            \
+        if constexpr (HINT) {                                                                         \
+            if (spartial) hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), lds, c.stream, \
+                                             x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial); \
+            else hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), lds, c.stream, \
+                                    x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);        \
+        } else {                                                                                      \
+            if (spartial) hipLaunchKernelGGL((k_welch_carry_nh<N, CPLX, S, true>), dim3(rp.blocks), dim3(C::WG), lds, c.stream, \
+                                             x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial); \
+            else hipLaunchKernelGGL((k_welch_carry_nh<N, CPLX, S, false>), dim3(rp.blocks), dim3(C::WG), lds, c.stream, \
+                                    x, win, nframes, rp.fpg, trend, xf.tb, partial, spartial);        \
+        }                                                                                             \
         return true;
     switch (shift) {
         CARRY_(4) CARRY_(8) CARRY_(16)
@@ -50,8 +57,8 @@ static bool try_carry_cog(LaunchCtx c, const void *x, const float *win, int hop,
     const int shift = hop / C::T;
 #define COG_(S)                                                                                       \
     case S:                                                                                           \
-        hipLaunchKernelGGL((k_welch_carry<N, CPLX, S, false, true>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF), \
-                           c.stream, x, win, nframes, rp.fpg, trend, xf.tb, reinterpret_cast<float *>(cog), (cf *)nullptr); \
+        hipLaunchKernelGGL((k_welch_carry_cog<N, CPLX, S>), dim3(rp.blocks), dim3(C::WG), C::lds_bytes(SP_CARRY_NBUF), \
+                           c.stream, x, win, nframes, rp.fpg, trend, xf.tb, cog);                    \
         return true;
     switch (shift) {
         COG_(4) COG_(8) COG_(16)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Instruction mix of the largest basic block (the frame loop) of one kernel in a device assembly file.
-  python tools/loopstat.py file.s 'k_welch_carry<4096, true, 8, true, false>'"""
+  python tools/loopstat.py file.s 'k_welch_carry<4096, true, 8, true>'"""
 import re, subprocess, sys
 from collections import Counter
 s = open(sys.argv[1]).read()

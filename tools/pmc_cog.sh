@@ -14,5 +14,5 @@ for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/pass$i -- python3 tools/cfgbench.py --only cog --reps 2 > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
 done
-python3 tools/pmc_summary.py $OUT "${2:-k_welch_carry<4096, true, 8, false, true>}" > $OUT/summary.txt 2>&1
+python3 tools/pmc_summary.py $OUT "${2:-k_welch_carry_cog<4096, true, 8>}" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
