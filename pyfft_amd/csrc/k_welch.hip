@@ -134,14 +134,26 @@ int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &
     return 0;
 }
 
+// smallest power-of-two transform that uses the hinted entry point of k_welch_rp (experiments: -DSP_RP_HINT_MIN=...)
+#ifndef SP_RP_HINT_MIN
+#define SP_RP_HINT_MIN 2048
+#endif
 // real input, two frames per transform (power only); rp partitions PAIRS of frames
 int launch_welch_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
                     const Xf &xf, float *partial, const RunPart &rp) {
 #define M_(XT)                                                                                        \
-    if (lin) hipLaunchKernelGGL((k_welch_rp<XT, true>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, \
-                                win, hop, nframes, rp.fpg, trend, xf.tb, partial);                    \
-    else hipLaunchKernelGGL((k_welch_rp<XT, false>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, \
-                            win, hop, nframes, rp.fpg, trend, xf.tb, partial);
+    if constexpr (XT::EXACT && XT::L >= SP_RP_HINT_MIN) {                                             \
+        /* (not for the linear-detrend variants: the hint makes them spill) */                        \
+        if (lin) hipLaunchKernelGGL((k_welch_rp<XT, true>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, \
+                                    x, win, hop, nframes, rp.fpg, trend, xf.tb, partial);             \
+        else hipLaunchKernelGGL((k_welch_rp_h<XT, false>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, \
+                                x, win, hop, nframes, rp.fpg, trend, xf.tb, partial);                 \
+    } else {                                                                                          \
+        if (lin) hipLaunchKernelGGL((k_welch_rp<XT, true>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, \
+                                    x, win, hop, nframes, rp.fpg, trend, xf.tb, partial);             \
+        else hipLaunchKernelGGL((k_welch_rp<XT, false>), dim3(rp.blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, \
+                                x, win, hop, nframes, rp.fpg, trend, xf.tb, partial);                 \
+    }
     SP_DISPATCH_X(xf, M_)
 #undef M_
     return 0;

@@ -431,10 +431,9 @@ __global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, 
 // formula holds.  Halves the transform count of real-valued Welch PSDs.
 // ------------------------------------------------------------------------------------------
 template <class X, bool LIN>
-__global__ __launch_bounds__(X::C::WG) void k_welch_rp(const float *__restrict__ x, const float *__restrict__ win, int hop,
-                                                        int64_t nframes, int64_t ppg /*pairs per group*/,
-                                                        const float *__restrict__ trend, XfTables tb,
-                                                        float *__restrict__ partial) {
+__device__ __forceinline__ void welch_rp_body(const float *__restrict__ x, const float *__restrict__ win, int hop,
+                                              int64_t nframes, int64_t ppg /*pairs per group*/,
+                                              const float *__restrict__ trend, XfTables tb, float *__restrict__ partial) {
     SP_KERNEL_PROLOGUE(X)
     float w[C::R], acc[C::R];
 #pragma unroll
@@ -475,6 +474,23 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_rp(const float *__restrict__
     }
 #pragma unroll
     for (int t = 0; t < C::R; ++t) partial[gid * X::L + tid + C::T * t] = acc[t];
+}
+// entry points: plain, and with the 2-waves-per-SIMD scheduling hint (see k_welch_carry).  Without the hint the 2048-point
+// kernel takes 165 VGPRs (3 waves per SIMD), with it 195 (2 waves) and is 13 % faster; 4096: -5 %, 8192: -2 %, 512: equal,
+// 1024: +2 % (profiles/r01_ab_waves_per_eu.txt) -- used from 2048 points up, and not for the linear-detrend variants, which
+// the hint makes spill.  The same hint on k_fft_c2c, k_stft_rp, k_fftfilt, k_pairspec and k_welch_csd_pair measured within
+// noise and is not applied.
+template <class X, bool LIN>
+__global__ __launch_bounds__(X::C::WG) void k_welch_rp(const float *__restrict__ x, const float *__restrict__ win, int hop,
+                                                        int64_t nframes, int64_t ppg, const float *__restrict__ trend,
+                                                        XfTables tb, float *__restrict__ partial) {
+    welch_rp_body<X, LIN>(x, win, hop, nframes, ppg, trend, tb, partial);
+}
+template <class X, bool LIN>
+__global__ __launch_bounds__(X::C::WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_welch_rp_h(
+    const float *__restrict__ x, const float *__restrict__ win, int hop, int64_t nframes, int64_t ppg,
+    const float *__restrict__ trend, XfTables tb, float *__restrict__ partial) {
+    welch_rp_body<X, LIN>(x, win, hop, nframes, ppg, trend, tb, partial);
 }
 
 // ------------------------------------------------------------------------------------------
