@@ -151,8 +151,9 @@ static int ew_blocks(int64_t n, int ncu) {
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
-int launch_transpose_c(LaunchCtx c, const cf *in, cf *out, int64_t rows, int64_t cols, int conj, float scale) {
-    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+int launch_transpose_c(LaunchCtx c, const cf *in, cf *out, int64_t rows, int64_t cols, int conj, float scale, int64_t batch) {
+    if (batch < 1 || batch > 65535 || (rows + 31) / 32 > 65535) return -1;
+    dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)batch);
     hipLaunchKernelGGL(k_transpose_c, grid, dim3(32, 8), 0, c.stream, in, out, rows, cols, conj, scale);
     return 0;
 }
@@ -160,16 +161,21 @@ int launch_pack_real(LaunchCtx c, const float *x, int64_t n_in, const double *me
     hipLaunchKernelGGL(k_pack_real, dim3(ew_blocks(L, c.ncu)), dim3(256), 0, c.stream, x, n_in, mean, L, out);
     return 0;
 }
-int launch_cmul_vec(LaunchCtx c, const cf *a, const cf *b, int64_t n, int conj_out, cf *out) {
-    hipLaunchKernelGGL(k_cmul_vec, dim3(ew_blocks(n, c.ncu)), dim3(256), 0, c.stream, a, b, n, conj_out, out);
+int launch_cmul_vec(LaunchCtx c, const cf *a, const cf *b, int64_t n, int conj_out, cf *out, int64_t batch) {
+    if (batch < 1 || batch > 65535) return -1;
+    hipLaunchKernelGGL(k_cmul_vec, dim3(ew_blocks(n, c.ncu), (unsigned)batch), dim3(256), 0, c.stream, a, b, n, conj_out, out);
     return 0;
 }
-int launch_blue_pre(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int64_t L, int conj_in, cf *out) {
-    hipLaunchKernelGGL(k_blue_pre, dim3(ew_blocks(L, c.ncu)), dim3(256), 0, c.stream, in, chirp, n, L, conj_in, out);
+int launch_blue_pre(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int64_t L, int conj_in, cf *out, int64_t batch) {
+    if (batch < 1 || batch > 65535) return -1;
+    hipLaunchKernelGGL(k_blue_pre, dim3(ew_blocks(L, c.ncu), (unsigned)batch), dim3(256), 0, c.stream, in, chirp, n, L, conj_in, out);
     return 0;
 }
-int launch_blue_post(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int conj_out, float scale, cf *out) {
-    hipLaunchKernelGGL(k_blue_post, dim3(ew_blocks(n, c.ncu)), dim3(256), 0, c.stream, in, chirp, n, conj_out, scale, out);
+int launch_blue_post(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int conj_out, float scale, cf *out, int64_t batch,
+                     int64_t in_ld) {
+    if (batch < 1 || batch > 65535) return -1;
+    hipLaunchKernelGGL(k_blue_post, dim3(ew_blocks(n, c.ncu), (unsigned)batch), dim3(256), 0, c.stream, in, chirp, n, conj_out, scale,
+                       out, in_ld);
     return 0;
 }
 int launch_hilbert_mask(LaunchCtx c, cf *X, int64_t n) {

@@ -220,6 +220,7 @@ template <class C> __device__ __forceinline__ void segment_detrend(cf (&v)[C::R]
 struct BigTw {
     const cf *hi, *lo;
     int lb;
+    int64_t mod;       // > 0: rows are numbered modulo `mod` (a batch of independent long transforms in one launch)
 };
 
 template <class X>
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in,
         if (bt.lo != nullptr) {
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
-                const int64_t m = bl * (int64_t)(tid + C::T * t);
+                const int64_t m = (bt.mod > 0 ? bl % bt.mod : bl) * (int64_t)(tid + C::T * t);
                 v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
             }
         }
@@ -1662,9 +1663,12 @@ __global__ void k_transpose(const E *__restrict__ in, E *__restrict__ out, int64
 }
 
 // complex transpose with out = scale * (conj ? conj(in) : in): first / last pass of the large FFT
+// blockIdx.z: matrix of a batch (contiguous rows*cols apart)
 static __global__ void k_transpose_c(const cf *__restrict__ in, cf *__restrict__ out, int64_t rows, int64_t cols,
                                      int conj, float scale) {
     __shared__ cf tile[32][33];
+    in += (int64_t)blockIdx.z * rows * cols;
+    out += (int64_t)blockIdx.z * rows * cols;
     const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
     const float sg = conj ? -scale : scale;
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {
@@ -1690,16 +1694,22 @@ static __global__ void k_pack_real(const float *__restrict__ x, int64_t n_in, co
         out[i] = i < n_in ? mk(x[i] - m, 0.f) : mk(0.f, 0.f);
 }
 // out[i] = a[i] * b[i] (optionally conj(a*b)), i < n
+// blockIdx.y: row of a batch (a and out n apart, b shared)
 static __global__ void k_cmul_vec(const cf *__restrict__ a, const cf *__restrict__ b, int64_t n, int conj_out,
                                   cf *__restrict__ out) {
+    a += (int64_t)blockIdx.y * n;
+    out += (int64_t)blockIdx.y * n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const cf p = cmul(a[i], b[i]);
         out[i] = conj_out ? cconj(p) : p;
     }
 }
 // Bluestein pre-multiply with zero padding: out[i] = i < n ? in[i]*chirp[i] : 0, i < L  (conj_in: use conj(in))
+// blockIdx.y: row of a batch (in n apart, out L apart)
 static __global__ void k_blue_pre(const cf *__restrict__ in, const cf *__restrict__ chirp, int64_t n, int64_t L,
                                   int conj_in, cf *__restrict__ out) {
+    in += (int64_t)blockIdx.y * n;
+    out += (int64_t)blockIdx.y * L;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < L; i += (int64_t)gridDim.x * blockDim.x) {
         if (i < n) {
             const cf a = in[i];
@@ -1710,8 +1720,11 @@ static __global__ void k_blue_pre(const cf *__restrict__ in, const cf *__restric
     }
 }
 // Bluestein post-multiply: out[i] = scale * conj?(in[i] * chirp[i]),  i < n
+// blockIdx.y: row of a batch (in in_ld apart, out n apart)
 static __global__ void k_blue_post(const cf *__restrict__ in, const cf *__restrict__ chirp, int64_t n, int conj_out,
-                                   float scale, cf *__restrict__ out) {
+                                   float scale, cf *__restrict__ out, int64_t in_ld) {
+    in += (int64_t)blockIdx.y * in_ld;
+    out += (int64_t)blockIdx.y * n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const cf p = cmul(in[i], chirp[i]);
         out[i] = mk(scale * p.x, conj_out ? -scale * p.y : scale * p.y);

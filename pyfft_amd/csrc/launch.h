@@ -84,18 +84,19 @@ inline int strided_blocks(int L, int64_t items, int ncu) {
 
 // every launcher returns 0 or -1 (unsupported L); kernel launch errors surface through hipGetLastError
 int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf,
-                   BigTw bt = BigTw{nullptr, nullptr, 0});
+                   BigTw bt = BigTw{nullptr, nullptr, 0, 0});
 int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_t in_rs, int64_t in_es, int64_t out_rs,
                        int64_t out_es, int conj_in, int conj_out, float scale, const Xf &xf, BigTw bt);
 int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
                     int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n = 0);
 int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B, int conj_out, float scale, const Xf &xf);
 // elementwise / transpose pieces of the long paths (k_fft.hip)
-int launch_transpose_c(LaunchCtx c, const cf *in, cf *out, int64_t rows, int64_t cols, int conj, float scale);
+int launch_transpose_c(LaunchCtx c, const cf *in, cf *out, int64_t rows, int64_t cols, int conj, float scale, int64_t batch = 1);
 int launch_pack_real(LaunchCtx c, const float *x, int64_t n_in, const double *mean, int64_t L, cf *out);
-int launch_cmul_vec(LaunchCtx c, const cf *a, const cf *b, int64_t n, int conj_out, cf *out);
-int launch_blue_pre(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int64_t L, int conj_in, cf *out);
-int launch_blue_post(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int conj_out, float scale, cf *out);
+int launch_cmul_vec(LaunchCtx c, const cf *a, const cf *b, int64_t n, int conj_out, cf *out, int64_t batch = 1);
+int launch_blue_pre(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int64_t L, int conj_in, cf *out, int64_t batch = 1);
+int launch_blue_post(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int conj_out, float scale, cf *out, int64_t batch = 1,
+                     int64_t in_ld = 0);
 int launch_hilbert_mask(LaunchCtx c, cf *X, int64_t n);
 int launch_xc_pack(LaunchCtx c, const float *x1, const float *x2, int64_t n, int64_t L, const double *mom, cf *z);
 int launch_xc_mid(LaunchCtx c, const cf *Z, int64_t L, cf *R);
@@ -157,6 +158,16 @@ int launch_xcorr(LaunchCtx c, const float *x1, const float *x2, int64_t n, const
 int launch_moments(LaunchCtx c, const void *x, bool cplx, int64_t n, int mode, double *partial_scratch, double *out_d,
                    float *trend_f, int nsignals = 1, int64_t x_cs = 0);
 int launch_transpose(LaunchCtx c, const void *in, void *out, int64_t rows, int64_t cols, int elem_bytes);
+// segments longer than one workgroup transform (k_long.hip); m frames starting at frame f0, rows S[m][nfft]
+int launch_long_segstats(LaunchCtx c, const void *x, bool cplx, int64_t f0, int64_t m, int hop, int nfft, int mode, float *rec);
+int launch_long_pack(LaunchCtx c, const void *x, bool cplx, const float *win, int nfft, int hop, int64_t f0, int64_t m,
+                     const float *trend, bool lin, const float *segrec, cf *S, double *pseg);
+int launch_long_acc_psd(LaunchCtx c, const cf *S, int64_t m, int nfft, double *acc);
+int launch_long_acc_csd(LaunchCtx c, const cf *Sx, const cf *Sy, int64_t m, int nfft, double *ayy, double *axy);
+int launch_long_finish(LaunchCtx c, const double *acc, int nfft, int sided, double scale, bool cplx, double *out);
+int launch_long_stft_out(LaunchCtx c, const cf *S, int64_t m, int nfft, int sided, float amp, int out_power, void *out,
+                         int64_t f0, int nb);
+int launch_long_cog(LaunchCtx c, const cf *S, int64_t m, int nfft, int klo, int khi, cf *acc, int64_t f0);
 
 // dispatch over the transform: MACRO(XTYPE) with XTYPE = XfPow2<L> or XfBlue<L>
 #define SP_CASE_P(Lv, MACRO) case Lv: { MACRO(XfPow2<Lv>) } break;

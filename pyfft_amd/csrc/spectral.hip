@@ -78,7 +78,7 @@ struct Ctx {
     std::map<int64_t, cf *> twiddles;   // L -> exp(-2 pi i m/L)
     std::map<int64_t, BlueTab> blue;    // n -> Bluestein tables
     Scratch in0, in1, out0, work, small, trends, onepass;
-    Scratch bigA, bigB, bigT, blueA, blueB;   // long (multi-kernel) paths
+    Scratch bigA, bigB, bigT, blueA, blueB, longrec;   // long (multi-kernel) paths
     Scratch cmS, cmT, cmG;                    // CSD matrix: spectra, bin-major spectra, float64 accumulator
     std::map<int64_t, BigTw> bigtw;           // N -> two-level twiddle tables of the multi-pass FFT
     std::map<int64_t, BlueTab> blue_big;      // n -> chirp[n], FFT_L(chirp*) (unscaled) for multi-pass Bluestein
@@ -374,6 +374,7 @@ int get_bigtw(int64_t N, BigTw *bt) {
     bt->hi = dhi;
     bt->lo = dlo;
     bt->lb = lb;
+    bt->mod = 0;
     g.bigtw[N] = *bt;
     return 0;
 }
@@ -385,28 +386,32 @@ bool big_three_pass(int64_t N) {
     return is_pow2(N) && N >= ((int64_t)1 << 20) && !env_flag("SP_BIGFFT_5PASS") && !env_flag("SP_BIGFFT_2PASS");
 }
 
-int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 0) {
+int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 0, int64_t batch = 1) {
     int lg = 0;
     while (((int64_t)1 << lg) < N) ++lg;
     if (((int64_t)1 << lg) != N || lg > SP_MAX_BIG_LOG2) return fail("internal: dev_fft_big_pow2(%lld)", (long long)N);
+    if (batch < 1) return fail("internal: dev_fft_big_pow2 batch");
     const int64_t N1 = (int64_t)1 << ((lg + 1) / 2), N2 = N / N1;
     Xf x1, x2;
     if (get_xf(N1, &x1) || get_xf(N2, &x2)) return -1;
     BigTw bt;
     if (get_bigtw(N, &bt)) return -1;
-    if (g.bigT.ensure(sizeof(cf) * (size_t)N)) return -1;
-    cf *tmp = (cf *)g.bigT.p;
     const float sc = inverse ? (float)(1.0 / (double)N) : 1.f;
     if (hmask && !big_three_pass(N)) return fail("internal: fused Hilbert mask needs the three-pass transform");
     if (big_three_pass(N)) {
-        // three passes over whole lines, N = A B C (kernels.h: k_fft_cols / k_fft_rows_rev)
+        // three passes over whole lines, N = A B C (kernels.h: k_fft_cols / k_fft_rows_rev); a batch runs row by row
+        // (each pass already fills the chip at these lengths)
+        if (g.bigT.ensure(sizeof(cf) * (size_t)N)) return -1;
+        cf *tmp = (cf *)g.bigT.p;
         const int la_ = (lg + 2) / 3, lb_ = (lg - la_ + 1) / 2, lc_ = lg - la_ - lb_;
         const int64_t A = (int64_t)1 << la_, B = (int64_t)1 << lb_, C = (int64_t)1 << lc_;
         Xf xa, xb, xc;
         if (get_xf(A, &xa) || get_xf(B, &xb) || get_xf(C, &xc)) return -1;
-        LAUNCHCHK(launch_fft_cols(lc(), in, tmp, B * C, 1, B * C, 0, 1, inverse, xa, bt, hmask ? N : 0));
-        LAUNCHCHK(launch_fft_cols(lc(), tmp, tmp, C, A, C, B * C, A, 0, xb, bt));
-        LAUNCHCHK(launch_fft_rows_rev(lc(), tmp, out, A, B, inverse, sc, xc));
+        for (int64_t b = 0; b < batch; ++b) {
+            LAUNCHCHK(launch_fft_cols(lc(), in + b * N, tmp, B * C, 1, B * C, 0, 1, inverse, xa, bt, hmask ? N : 0));
+            LAUNCHCHK(launch_fft_cols(lc(), tmp, tmp, C, A, C, B * C, A, 0, xb, bt));
+            LAUNCHCHK(launch_fft_rows_rev(lc(), tmp, out + b * N, A, B, inverse, sc, xc));
+        }
         return 0;
     }
     if (env_flag("SP_BIGFFT_2PASS") && N1 >= 16 && N2 >= 16) {
@@ -415,24 +420,36 @@ int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 
         // [N1][N2], n = n1 N2 + n2):
         //   A: for every column n2: FFT over n1, times W_N^{n2 k1}  -> tmp[n2][k1]            (column read, row write)
         //   B: for every column k1 of tmp: FFT over n2               -> out[k1 + N1 k2]       (column read, column write)
-        LAUNCHCHK(launch_fft_strided(lc(), in, tmp, N2, 1, N2, N1, 1, inverse, 0, 1.f, x1, bt));
-        LAUNCHCHK(launch_fft_strided(lc(), tmp, out, N1, 1, N1, 1, N1, 0, inverse, sc, x2, BigTw{nullptr, nullptr, 0}));
+        if (g.bigT.ensure(sizeof(cf) * (size_t)N)) return -1;
+        cf *tmp = (cf *)g.bigT.p;
+        for (int64_t b = 0; b < batch; ++b) {
+            LAUNCHCHK(launch_fft_strided(lc(), in + b * N, tmp, N2, 1, N2, N1, 1, inverse, 0, 1.f, x1, bt));
+            LAUNCHCHK(launch_fft_strided(lc(), tmp, out + b * N, N1, 1, N1, 1, N1, 0, inverse, sc, x2, BigTw{nullptr, nullptr, 0, 0}));
+        }
         return 0;
     }
+    // N = 2^k, 2^14 <= N < 2^20:  x viewed as [N1][N2]; transpose, N2 row FFTs of N1 (+ twiddle W_N^{n2 k1}), transpose,
+    // N1 row FFTs of N2, transpose back to natural order: 5 passes over the data (80 B / point).  The whole batch of
+    // transforms goes through each of the five launches together (rows numbered modulo N2 for the twiddle).
+    if (batch > 65535) return fail("internal: dev_fft_big_pow2 batch %lld", (long long)batch);
+    if (g.bigT.ensure(sizeof(cf) * (size_t)N * (size_t)batch)) return -1;
+    cf *tmp = (cf *)g.bigT.p;
+    BigTw btb = bt;
+    btb.mod = N2;
     if (in != out) {
-        LAUNCHCHK(launch_transpose_c(lc(), in, out, N1, N2, inverse, 1.f));        // out[n2][n1]
-        LAUNCHCHK(launch_fft_c2c(lc(), out, out, N2, 0, x1, bt));                   // A[n2][k1] W^{n2 k1}
-        LAUNCHCHK(launch_transpose_c(lc(), out, tmp, N2, N1, 0, 1.f));              // tmp[k1][n2]
-        LAUNCHCHK(launch_fft_c2c(lc(), tmp, tmp, N1, 0, x2));                       // B[k1][k2]
-        LAUNCHCHK(launch_transpose_c(lc(), tmp, out, N1, N2, inverse, sc));         // out[k2][k1]
+        LAUNCHCHK(launch_transpose_c(lc(), in, out, N1, N2, inverse, 1.f, batch));        // out[n2][n1]
+        LAUNCHCHK(launch_fft_c2c(lc(), out, out, N2 * batch, 0, x1, btb));                 // A[n2][k1] W^{n2 k1}
+        LAUNCHCHK(launch_transpose_c(lc(), out, tmp, N2, N1, 0, 1.f, batch));              // tmp[k1][n2]
+        LAUNCHCHK(launch_fft_c2c(lc(), tmp, tmp, N1 * batch, 0, x2));                      // B[k1][k2]
+        LAUNCHCHK(launch_transpose_c(lc(), tmp, out, N1, N2, inverse, sc, batch));         // out[k2][k1]
     } else {
-        if (g.blueB.ensure(sizeof(cf) * (size_t)N)) return -1;     // second temporary for the in-place form
+        if (g.blueB.ensure(sizeof(cf) * (size_t)N * (size_t)batch)) return -1;     // second temporary for the in-place form
         cf *t2 = (cf *)g.blueB.p;
-        LAUNCHCHK(launch_transpose_c(lc(), in, tmp, N1, N2, inverse, 1.f));
-        LAUNCHCHK(launch_fft_c2c(lc(), tmp, tmp, N2, 0, x1, bt));
-        LAUNCHCHK(launch_transpose_c(lc(), tmp, t2, N2, N1, 0, 1.f));
-        LAUNCHCHK(launch_fft_c2c(lc(), t2, t2, N1, 0, x2));
-        LAUNCHCHK(launch_transpose_c(lc(), t2, out, N1, N2, inverse, sc));
+        LAUNCHCHK(launch_transpose_c(lc(), in, tmp, N1, N2, inverse, 1.f, batch));
+        LAUNCHCHK(launch_fft_c2c(lc(), tmp, tmp, N2 * batch, 0, x1, btb));
+        LAUNCHCHK(launch_transpose_c(lc(), tmp, t2, N2, N1, 0, 1.f, batch));
+        LAUNCHCHK(launch_fft_c2c(lc(), t2, t2, N1 * batch, 0, x2));
+        LAUNCHCHK(launch_transpose_c(lc(), t2, out, N1, N2, inverse, sc, batch));
     }
     return 0;
 }
@@ -466,7 +483,9 @@ int get_blue_big(int64_t n, BlueTab *t) {
     return 0;
 }
 
-// any length, device pointers.  in == out allowed.
+// any length, device pointers.  in == out allowed.  Batches of long transforms go through the multi-kernel paths in
+// slices of at most SP_LONG_SLICE_BYTES of work buffer (every launch then covers a whole slice).
+#define SP_LONG_SLICE_BYTES ((size_t)256 << 20)
 int dev_fft_any(const cf *in, cf *out, int64_t n, int64_t batch, int inverse) {
     if (n == 1) {
         if (in != out) HIPCHK(hipMemcpyAsync(out, in, sizeof(cf) * (size_t)batch, hipMemcpyDeviceToDevice, g.stream));
@@ -478,27 +497,59 @@ int dev_fft_any(const cf *in, cf *out, int64_t n, int64_t batch, int inverse) {
         LAUNCHCHK(launch_fft_c2c(lc(), in, out, batch, inverse, xf));
         return 0;
     }
+    const int64_t L = is_pow2(n) ? n : next_pow2(2 * n - 1);
+    if (L > ((int64_t)1 << SP_MAX_BIG_LOG2))
+        return fail("transform length %lld needs a %lld-point multi-pass transform; the limit is 2^%d", (long long)n,
+                    (long long)L, SP_MAX_BIG_LOG2);
+    int64_t slice = (int64_t)(SP_LONG_SLICE_BYTES / (sizeof(cf) * (size_t)L));
+    if (slice < 1) slice = 1;
+    if (slice > 32768) slice = 32768;
     if (is_pow2(n)) {
-        if (n > ((int64_t)1 << SP_MAX_BIG_LOG2)) return fail("transform length %lld exceeds 2^%d", (long long)n, SP_MAX_BIG_LOG2);
-        for (int64_t b = 0; b < batch; ++b)
-            if (dev_fft_big_pow2(in + b * n, out + b * n, n, inverse)) return -1;
+        for (int64_t b0 = 0; b0 < batch; b0 += slice) {
+            const int64_t m = batch - b0 < slice ? batch - b0 : slice;
+            if (dev_fft_big_pow2(in + b0 * n, out + b0 * n, n, inverse, 0, m)) return -1;
+        }
         return 0;
     }
-    const int64_t L = next_pow2(2 * n - 1);
-    if (L > ((int64_t)1 << SP_MAX_BIG_LOG2))
-        return fail("transform length %lld needs a 2^%d-point chirp-z; the limit is 2^%d", (long long)n, 0, SP_MAX_BIG_LOG2);
     BlueTab bt;
     if (get_blue_big(n, &bt)) return -1;
-    if (g.blueA.ensure(sizeof(cf) * (size_t)L)) return -1;
+    if (slice > batch) slice = batch;
+    if (g.blueA.ensure(sizeof(cf) * (size_t)L * (size_t)slice)) return -1;
     cf *A = (cf *)g.blueA.p;
-    for (int64_t b = 0; b < batch; ++b) {
-        LAUNCHCHK(launch_blue_pre(lc(), in + b * n, bt.chirp, n, L, inverse, A));
-        if (dev_fft_big_pow2(A, A, L, 0)) return -1;
-        LAUNCHCHK(launch_cmul_vec(lc(), A, bt.bf, L, 0, A));
-        if (dev_fft_big_pow2(A, A, L, 1)) return -1;
-        LAUNCHCHK(launch_blue_post(lc(), A, bt.chirp, n, inverse, inverse ? (float)(1.0 / (double)n) : 1.f, out + b * n));
+    for (int64_t b0 = 0; b0 < batch; b0 += slice) {
+        const int64_t m = batch - b0 < slice ? batch - b0 : slice;
+        LAUNCHCHK(launch_blue_pre(lc(), in + b0 * n, bt.chirp, n, L, inverse, A, m));
+        if (dev_fft_big_pow2(A, A, L, 0, 0, m)) return -1;
+        LAUNCHCHK(launch_cmul_vec(lc(), A, bt.bf, L, 0, A, m));
+        if (dev_fft_big_pow2(A, A, L, 1, 0, m)) return -1;
+        LAUNCHCHK(launch_blue_post(lc(), A, bt.chirp, n, inverse, inverse ? (float)(1.0 / (double)n) : 1.f, out + b0 * n, m, L));
     }
     return 0;
+}
+
+
+// ---- segments longer than one workgroup transform (k_long.hip) -----------------------------------
+// frames per chunk: the chunk's spectra (m x nfft complex64) stay below SP_LONG_CHUNK_BYTES
+#define SP_LONG_CHUNK_BYTES ((size_t)192 << 20)
+int64_t long_chunk_frames(int nfft, int64_t nframes) {
+    int64_t m = (int64_t)(SP_LONG_CHUNK_BYTES / (sizeof(cf) * (size_t)nfft));
+    if (m > 32768) m = 32768;
+    if (m > nframes) m = nframes;
+    if (m < 1) m = 1;
+    return m;
+}
+// spectra of frames [f0, f0+m) of one signal -> buf[m][nfft] (natural bin order, unscaled); segmean: 1 / 2 = every
+// frame's own mean / least-squares line is removed first; pseg_d (optional, zeroed): per-frame time-domain power
+int long_spectra(const void *xd, bool cplx, const float *win_d, int nfft, int hop, int64_t f0, int64_t m, const float *trend,
+                 bool lin, int segmean, cf *buf, double *pseg_d) {
+    const float *rec = nullptr;
+    if (segmean) {
+        if (g.longrec.ensure(sizeof(float) * 4 * (size_t)m)) return -1;
+        LAUNCHCHK(launch_long_segstats(lc(), xd, cplx, f0, m, hop, nfft, segmean, (float *)g.longrec.p));
+        rec = (const float *)g.longrec.p;
+    }
+    LAUNCHCHK(launch_long_pack(lc(), xd, cplx, win_d, nfft, hop, f0, m, trend, lin, rec, buf, pseg_d));
+    return dev_fft_any(buf, buf, nfft, m, 0);
 }
 
 
@@ -648,6 +699,7 @@ void sp_shutdown(void) {
     g.bigT.release();
     g.blueA.release();
     g.blueB.release();
+    g.longrec.release();
     for (auto &kv : g.bigtw) {
         (void)hipFree((void *)kv.second.hi);
         (void)hipFree((void *)kv.second.lo);
@@ -766,8 +818,9 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         mean_re = mean_im = 0.0;
     }
     std::lock_guard<std::mutex> lk(g.mu);
+    const bool lng = !wg_capable(nfft);          // segment longer than one workgroup transform: multi-kernel path
     Xf xf;
-    if (get_xf(nfft, &xf)) return -1;
+    if (!lng && get_xf(nfft, &xf)) return -1;
     const bool cplx = x_dtype == SP_DTYPE_C64;
     const size_t esz = cplx ? 8 : 4;
     const void *xd = x;
@@ -783,7 +836,25 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         out_d = (double *)g.out0.p;
     }
     const bool allow_carry = !env_flag("SP_WELCH_GENERIC");
-    if (cplx && detrend == SP_DETREND_MEAN && allow_carry && !env_flag("SP_WELCH_TWOPASS") &&
+    if (lng) {
+        void *win_d;
+        if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
+        TrendBuf tb;
+        if (get_trendbuf(1, &tb)) return -1;
+        if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
+        const int64_t mc = long_chunk_frames(nfft, nframes);
+        if (g.bigA.ensure(sizeof(cf) * (size_t)mc * (size_t)nfft) || g.work.ensure(sizeof(double) * (size_t)nfft)) return -1;
+        cf *S = (cf *)g.bigA.p;
+        double *acc = (double *)g.work.p;
+        HIPCHK(hipMemsetAsync(acc, 0, sizeof(double) * (size_t)nfft, g.stream));
+        for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
+            const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
+            if (long_spectra(xd, cplx, (const float *)win_d, nfft, hop, f0, m, tb.f, detrend == 2, segmean, S, nullptr)) return -1;
+            LAUNCHCHK(launch_long_acc_psd(lc(), S, m, nfft, acc));
+        }
+        LAUNCHCHK(launch_long_finish(lc(), acc, nfft, sided, scale / (double)nframes, false, out_d));
+        g.last_kernel = "k_long_acc_psd";
+    } else if (cplx && detrend == SP_DETREND_MEAN && allow_carry && !env_flag("SP_WELCH_TWOPASS") &&
         welch_carry_eligible(xf, hop, false)) {
         // global-mean detrend in ONE pass over the signal (estimate + exact correction in the epilogue)
         if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nsig, false)) return -1;
@@ -943,8 +1014,9 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         mean_x = mean_y = nullptr;
     }
     std::lock_guard<std::mutex> lk(g.mu);
+    const bool lng = !wg_capable(nfft);
     Xf xf;
-    if (get_xf(nfft, &xf)) return -1;
+    if (!lng && get_xf(nfft, &xf)) return -1;
     const bool cplx = dtype == SP_DTYPE_C64;
     const size_t esz = cplx ? 8 : 4;
     const void *xd = x, *yd = y;
@@ -979,6 +1051,41 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         pxx_d = (double *)g.out0.p;
         pyy_d = pxx_d + nb;
         pxy_d = pyy_d + nb * nch;
+    }
+    if (lng) {
+        // long segments: spectra of a chunk of frames of x, then of every channel against them (k_long.hip)
+        const int64_t mc = long_chunk_frames(nfft, nframes);
+        const size_t nf = (size_t)nfft;
+        if (g.bigA.ensure(sizeof(cf) * (size_t)mc * nf) || g.bigB.ensure(sizeof(cf) * (size_t)mc * nf) ||
+            g.work.ensure(sizeof(double) * nf * (1 + 3 * (size_t)nch)))
+            return -1;
+        cf *Sx = (cf *)g.bigA.p, *Sy = (cf *)g.bigB.p;
+        double *axx = (double *)g.work.p, *ayy = axx + nf, *axy = ayy + nf * (size_t)nch;
+        HIPCHK(hipMemsetAsync(axx, 0, sizeof(double) * nf * (1 + 3 * (size_t)nch), g.stream));
+        for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
+            const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
+            if (long_spectra(xd, cplx, (const float *)win_d, nfft, hop, f0, m, tb.f, detrend == 2, segmean, Sx, nullptr)) return -1;
+            LAUNCHCHK(launch_long_acc_psd(lc(), Sx, m, nfft, axx));
+            for (int c = 0; c < nch; ++c) {
+                if (long_spectra((const char *)yd + esz * (size_t)y_ld * (size_t)c, cplx, (const float *)win_d, nfft, hop, f0, m,
+                                 tb.f + 4 * (c + 1), detrend == 2, segmean, Sy, nullptr))
+                    return -1;
+                LAUNCHCHK(launch_long_acc_csd(lc(), Sx, Sy, m, nfft, ayy + nf * (size_t)c, axy + 2 * nf * (size_t)c));
+            }
+        }
+        const double sc = scale / (double)nframes;
+        LAUNCHCHK(launch_long_finish(lc(), axx, nfft, sided, sc, false, pxx_d));
+        for (int c = 0; c < nch; ++c) {
+            LAUNCHCHK(launch_long_finish(lc(), ayy + nf * (size_t)c, nfft, sided, sc, false, pyy_d + nb * (size_t)c));
+            LAUNCHCHK(launch_long_finish(lc(), axy + 2 * nf * (size_t)c, nfft, sided, sc, true, pxy_d + 2 * nb * (size_t)c));
+        }
+        if (!mem) {
+            HIPCHK(hipMemcpyAsync(pxx, pxx_d, sizeof(double) * nb, hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipMemcpyAsync(pyy, pyy_d, sizeof(double) * nb * nch, hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipMemcpyAsync(pxy, pxy_d, sizeof(double) * nb * nch * 2, hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+        }
+        return 0;
     }
     const RunPart rp = run_partition_2d(xf.L, nframes, g.ncu, nch);
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L * 4 * (size_t)nch)) return -1;
@@ -1184,8 +1291,9 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
         mean_re = mean_im = 0.0;
     }
     std::lock_guard<std::mutex> lk(g.mu);
+    const bool lng = !wg_capable(nfft);
     Xf xf;
-    if (get_xf(nfft, &xf)) return -1;
+    if (!lng && get_xf(nfft, &xf)) return -1;
     const bool cplx = x_dtype == SP_DTYPE_C64;
     const size_t esz = cplx ? 8 : 4;
     const size_t osz = out_kind ? 4 : 8;
@@ -1215,8 +1323,17 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
         fm = g.work.p;
     }
     if (pseg_d) HIPCHK(hipMemsetAsync(pseg_d, 0, sizeof(double) * (size_t)nframes, g.stream));
-    const bool pair = !cplx && !segmean && !xf.blue && xf.L >= 32 && nframes >= 2 && !env_flag("SP_NO_REALPAIR");
-    if (pair) {
+    const bool pair = !lng && !cplx && !segmean && !xf.blue && xf.L >= 32 && nframes >= 2 && !env_flag("SP_NO_REALPAIR");
+    if (lng) {
+        const int64_t mc = long_chunk_frames(nfft, nframes);
+        if (g.bigA.ensure(sizeof(cf) * (size_t)mc * (size_t)nfft)) return -1;
+        cf *S = (cf *)g.bigA.p;
+        for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
+            const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
+            if (long_spectra(xd, cplx, (const float *)win_d, nfft, hop, f0, m, tb.f, detrend == 2, segmean, S, pseg_d)) return -1;
+            LAUNCHCHK(launch_long_stft_out(lc(), S, m, nfft, sided, (float)amp_scale, out_kind, fm, f0, (int)nb));
+        }
+    } else if (pair) {
         const RunPart rp = run_partition(xf.L, (nframes + 1) / 2, g.ncu);
         LAUNCHCHK(launch_stft_rp(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, sided,
                                  (float)amp_scale, out_kind, fm, pseg_d));
@@ -1247,8 +1364,9 @@ int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int 
         mean_re = mean_im = 0.0;
     }
     std::lock_guard<std::mutex> lk(g.mu);
+    const bool lng = !wg_capable(nfft);
     Xf xf;
-    if (get_xf(nfft, &xf)) return -1;
+    if (!lng && get_xf(nfft, &xf)) return -1;
     const bool cplx = x_dtype == SP_DTYPE_C64;
     const size_t esz = cplx ? 8 : 4;
     const void *xd = x;
@@ -1269,7 +1387,7 @@ int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int 
     const int klo = (int)std::ceil(fmin / df - eps);
     const double kh = std::floor(fmax / df + eps);
     const int khi = kh > (double)nfft ? nfft : (int)kh;
-    const int wpf = xf.L / 16 >= 64 ? xf.L / 16 / 64 : 1;           // waves per frame: one (num, den) slot each
+    const int wpf = lng ? 1 : (xf.L / 16 >= 64 ? xf.L / 16 / 64 : 1);   // waves per frame: one (num, den) slot each
     const size_t abytes = sizeof(cf) * (size_t)wpf * (size_t)nframes;
     if (g.work.ensure(abytes)) return -1;
     cf *acc = (cf *)g.work.p;
@@ -1278,16 +1396,27 @@ int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int 
         if (g.out0.ensure(sizeof(double) * (size_t)nframes)) return -1;
         fin = (double *)g.out0.p;
     }
-    const RunPart rp = run_partition(xf.L, nframes, g.ncu);
-    // streaming form (every sample read once, the overlap carried in registers) when the shape allows; SP_COG_GENERIC=1
-    // forces the generic frame kernel (A/B test)
-    int generic = 1;
-    if (!segmean && detrend != 2 && !env_flag("SP_COG_GENERIC"))
-        generic = launch_cog_carry(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, acc, rp, klo, khi);
-    if (generic < 0) return fail("sp_stft_cog: launch failed");
-    if (generic)
-        LAUNCHCHK(launch_stft(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, 2, 1.f, 1, nullptr,
-                              nullptr, segmean, acc, klo, khi));
+    if (lng) {
+        const int64_t mc = long_chunk_frames(nfft, nframes);
+        if (g.bigA.ensure(sizeof(cf) * (size_t)mc * (size_t)nfft)) return -1;
+        cf *S = (cf *)g.bigA.p;
+        for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
+            const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
+            if (long_spectra(xd, cplx, (const float *)win_d, nfft, hop, f0, m, tb.f, detrend == 2, segmean, S, nullptr)) return -1;
+            LAUNCHCHK(launch_long_cog(lc(), S, m, nfft, klo, khi, acc, f0));
+        }
+    } else {
+        const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+        // streaming form (every sample read once, the overlap carried in registers) when the shape allows; SP_COG_GENERIC=1
+        // forces the generic frame kernel (A/B test)
+        int generic = 1;
+        if (!segmean && detrend != 2 && !env_flag("SP_COG_GENERIC"))
+            generic = launch_cog_carry(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, acc, rp, klo, khi);
+        if (generic < 0) return fail("sp_stft_cog: launch failed");
+        if (generic)
+            LAUNCHCHK(launch_stft(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, 2, 1.f, 1, nullptr,
+                                  nullptr, segmean, acc, klo, khi));
+    }
     LAUNCHCHK(launch_cog_finish(lc(), acc, wpf, nframes, df, fin));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(cog_out, fin, sizeof(double) * (size_t)nframes, hipMemcpyDeviceToHost, g.stream));

@@ -49,10 +49,12 @@ def test_limits_raise_cleanly(P):
     E = P.engine
     Err = P._ffi.SpectralError
     x = np.zeros(40000, dtype=np.float32)
-    with pytest.raises(Err, match="not supported"):
-        E.welch_psd(x, np.ones(16384), 8192, 2)                  # segment longer than one workgroup handles
-    with pytest.raises(Err, match="not supported"):
-        E.welch_psd(x, np.ones(5000), 2500, 3)                   # non power of two above 4096
+    # segments longer than one workgroup transform go through the multi-kernel path (tests/test_gpu_long.py) ...
+    assert np.all(E.welch_psd(x + 1, np.ones(16384), 8192, 2, detrend=False, sided=E.SIDED_RAW)[1:] < 1e-3)
+    assert E.welch_psd(x, np.ones(5000), 2500, 3).shape == (5000,)
+    # ... up to a 2^26-point transform (chirp-z needs next_pow2(2n-1) points)
+    with pytest.raises(Err, match="limit is 2\\^26"):
+        E.fft(np.zeros((1 << 25) + 1, dtype=np.complex64))
     with pytest.raises(Err):
         E.welch_psd(x, np.ones(256), 128, 100000)                # frames run past the end
     with pytest.raises(Err):

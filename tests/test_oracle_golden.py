@@ -341,3 +341,67 @@ def test_fft_pwelch_ntmodel_branch(tag):
         O.fft_pwelch(t, xm, y[:, 0], tb, Navr=37)
     with pytest.raises(ValueError):
         O.fft_pwelch(t, xm, y[:, 0], None)
+
+
+# ------------------------------------------------------------------ long segments (the reference's default Navr=8 regime)
+def _long_inputs():
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import inputs_long
+    return inputs_long
+
+
+def test_fft_pwelch_long_navr8():
+    """test_fftanal's own call shape (fft_analysis.py:2950-2993): N = 2^19, Navr = 8 -> nwins = 116 508"""
+    g = load_golden("pwelch_long_navr8")
+    tvec, sigx, sigy = _long_inputs().long_signals(int(g["N"]), float(g["df"]), int(g["seed"]))
+    freq, Pxy, Pxx, Pyy, Cxy, phi, info = O.fft_pwelch(tvec, sigx, sigy, tbounds=[tvec[0], tvec[-1]], Navr=8,
+                                                        windowfunction="hamming", detrend_style=1, onesided=True)
+    assert int(info["nwins"]) == int(g["nwins"]) == 116508 and int(info["Navr"]) == 8
+    assert int(info["noverlap"]) == int(g["noverlap"]) and list(info["ibnds"]) == list(g["ibnds"])
+    for k in ("S1", "S2", "ENBW", "NENBW", "Fs"):
+        close(info[k], g[k])
+    ib, il = g["ibin"], g["ilag"]
+    assert Pxx.shape[0] == int(g["nbins"])
+    close(freq[ib], g["freq"])
+    at = 1e-9 * float(np.max(np.abs(g["Pxx"])))
+    for name, got in (("Pxx", Pxx), ("Pyy", Pyy), ("Pxy", Pxy)):
+        close(np.asarray(got).reshape(len(freq), -1)[ib, 0], g[name], rtol=1e-8, atol=at)
+    close(np.asarray(Cxy).reshape(len(freq), -1)[ib, 0], g["Cxy"], rtol=1e-7, atol=1e-9)
+    close(np.asarray(phi).reshape(len(freq), -1)[ib, 0], g["phi_xy"], rtol=1e-6, atol=1e-7)
+    for k in ("Lxx", "Lyy", "Lxy", "varPxx"):
+        gk = g["info_" + k]
+        close(np.asarray(info[k]).reshape(len(freq), -1)[ib, 0], gk, rtol=1e-7, atol=1e-9 * float(np.max(np.abs(gk))))
+    for k in ("Rxx", "Ryy", "Rxy", "corrcoef", "lags"):
+        gk = g["info_" + k]
+        a = np.asarray(info[k])
+        close(a.reshape(a.shape[0], -1)[il, 0], gk, rtol=1e-7, atol=1e-9 * float(np.max(np.abs(gk))))
+
+
+def test_class_welch_long_navr8():
+    g = load_golden("welch_class_long_navr8")
+    tvec, sigx, sigy = _long_inputs().long_signals(int(g["N"]), float(g["df"]), int(g["seed"]))
+    r = O.pwelch_class(tvec, sigx, sigy, Navr=8, windowfunction="hamming", windowoverlap=0.5, tbounds=[tvec[0], tvec[-1]])
+    assert r["onesided"] and r["nwins"] == int(g["nwins"]) and r["Navr"] == int(g["Navr"])
+    ib = g["ibin"]
+    close(r["freq"][ib], g["freq"])
+    close(r["tseg"], g["tseg"])
+    for k in ("Pxx", "Pyy", "Pxy"):
+        close(np.asarray(r[k])[ib], g[k], rtol=1e-8, atol=1e-9 * float(np.max(np.abs(g[k]))))
+    sc = float(np.abs(g["Xseg_first"]).max())
+    close(r["Xseg"][0][ib], g["Xseg_first"], rtol=1e-8, atol=1e-9 * sc)
+    close(r["Xseg"][-1][ib], g["Xseg_last"], rtol=1e-8, atol=1e-9 * sc)
+    close(r["Yseg"][0][ib], g["Yseg_first"], rtol=1e-8, atol=1e-9 * sc)
+    close(r["Xpow"], g["Xpow"], rtol=1e-9)
+
+
+def test_stft_long_windows():
+    g = load_golden("stft_long_n10000")
+    k, xs = _long_inputs().stft_long_signal(int(g["n"]), int(g["seed"]))
+    r = O.stft(k, xs, tper=10000.5, windowfunction="Hanning", windowoverlap=0.5)
+    assert r["nwins"] == int(g["nwins"]) == 10000 and r["Navr"] == int(g["Navr"])
+    ib = g["ibin"]
+    close(r["freq"][ib], g["freq"])
+    close(r["tseg"], g["tseg"])
+    close(np.asarray(r["Xseg"])[:, ib], g["Xseg_sub"], rtol=1e-8, atol=1e-9 * float(np.abs(g["Xseg_sub"]).max()))
+    close(np.asarray(r["Pxx"])[ib], g["Pxx"], rtol=1e-8, atol=1e-9 * float(np.abs(g["Pxx"]).max()))
