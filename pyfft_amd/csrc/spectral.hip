@@ -1,6 +1,7 @@
 // spectral.hip -- C ABI (include/spectral.h) over the gfx950 kernels (kernels.h via launch.h).
 #include "../../include/spectral.h"
 #include "launch.h"
+#include "table_cache.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -78,13 +79,14 @@ struct Ctx {
     std::map<int64_t, cf *> twiddles;   // L -> exp(-2 pi i m/L)
     std::map<int64_t, BlueTab> blue;    // n -> Bluestein tables
     Scratch in0, in1, out0, work, small, trends, onepass;
+    Scratch pend_trend;                       // trend record a pending sp_welch_accum keeps until sp_welch_finish
     Scratch bigA, bigB, bigT, blueA, blueB, longrec;   // long (multi-kernel) paths
     Scratch cmS, cmT, cmG;                    // CSD matrix: spectra, bin-major spectra, float64 accumulator
     std::map<int64_t, BigTw> bigtw;           // N -> two-level twiddle tables of the multi-pass FFT
     std::map<int64_t, BlueTab> blue_big;      // n -> chirp[n], FFT_L(chirp*) (unscaled) for multi-pass Bluestein
     std::mutex mu;
     bool profile = false, prof_valid = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_sw = nullptr;
     const char *last_kernel = "";
 } g;
 
@@ -202,11 +204,17 @@ int get_xf(int64_t n, Xf *xf) {
 // Small host tables (windows, filter spectra) live in a content-keyed device cache: a table is uploaded
 // once into its own allocation and never overwritten, so asynchronous (mem=1) callers can reuse the
 // host buffer immediately and repeated calls with the same window cost no copy and no synchronisation.
-struct TableEntry {
-    void *dev;
-    size_t bytes;
+// (bookkeeping and eviction policy: table_cache.h.)  A miss on a full cache drops the least recently used entry that
+// the current API call has not touched and that a pending sp_welch_accum does not hold; the device is synchronised
+// before the entry is freed, because asynchronous (mem=1) work of an earlier call may still read it.
+TableCache g_tables;
+
+// every C-ABI entry point that touches device state holds this for its whole body: the library lock, and the start of
+// a new "current call" for the table cache
+struct ApiLock {
+    std::lock_guard<std::mutex> lk;
+    ApiLock() : lk(g.mu) { g_tables.begin_call(); }
 };
-std::map<uint64_t, TableEntry> g_tables;
 
 // content hash of a host table (FNV-1a style, 8 bytes per step: a 4096-point window hashes in ~1 us)
 uint64_t fnv1a(const void *p, size_t n, uint64_t h) {
@@ -227,8 +235,8 @@ uint64_t fnv1a(const void *p, size_t n, uint64_t h) {
 }
 
 void tables_release() {
-    for (auto &kv : g_tables) (void)hipFree(kv.second.dev);
-    g_tables.clear();
+    for (auto &kv : g_tables.map) (void)hipFree(kv.second.dev);
+    g_tables.map.clear();
 }
 
 // device table keyed by the CONTENT of `key_data`.  upload != null: a miss uploads `bytes` from it; upload == null: a
@@ -236,20 +244,28 @@ void tables_release() {
 int get_table_keyed(uint64_t kind, const void *key_data, size_t key_bytes, const void *upload, size_t bytes, void **dev,
                     bool *fresh) {
     const uint64_t key = fnv1a(key_data, key_bytes, 1469598103934665603ull ^ (kind * 0x9E3779B97F4A7C15ull) ^ bytes);
-    auto it = g_tables.find(key);
-    if (it != g_tables.end() && it->second.bytes == bytes) {
-        *dev = it->second.dev;
+    if (TableEntry *e = g_tables.find(key, bytes)) {
+        *dev = e->dev;
         if (fresh) *fresh = false;
         return 0;
     }
-    if (g_tables.size() >= 64) {
-        HIPCHK(hipStreamSynchronize(g.stream));
-        tables_release();
+    if (g_tables.full()) {
+        const void *pinned[2] = {g_pend.valid ? (const void *)g_pend.win_d : nullptr, g_pend.valid ? (const void *)g_pend.Wf : nullptr};
+        uint64_t victim;
+        bool synced = false;
+        while (g_tables.full() && g_tables.pick_victim(pinned, 2, &victim)) {
+            if (!synced) HIPCHK(hipDeviceSynchronize());
+            synced = true;
+            (void)hipFree(g_tables.erase(victim));
+        }   // nothing evictable: every entry is in use by this call -- grow past the cap rather than free live memory
     }
     void *d = nullptr;
     HIPCHK(hipMalloc(&d, bytes));
     if (upload) HIPCHK(hipMemcpy(d, upload, bytes, hipMemcpyHostToDevice));
-    g_tables[key] = TableEntry{d, bytes};
+    if (void *old = g_tables.insert(key, d, bytes)) {
+        HIPCHK(hipDeviceSynchronize());
+        (void)hipFree(old);
+    }
     *dev = d;
     if (fresh) *fresh = true;
     return 0;
@@ -581,8 +597,9 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
     void *Wf_d;
     if (get_window_spectrum(win, nfft, xf, &Wf_d)) return -1;
-    TrendBuf tb;
-    if (get_trendbuf(1, &tb)) return -1;
+    // its own trend record: calls between sp_welch_accum and sp_welch_finish reuse the shared one
+    if (g.pend_trend.ensure(256)) return -1;
+    TrendBuf tb{(float *)g.pend_trend.p, nullptr};
     const RunPart rp = run_partition(xf.L, nframes, g.ncu);
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
     const size_t sp_bytes = sizeof(cf) * (size_t)rp.groups * (size_t)hop;
@@ -691,6 +708,7 @@ void sp_shutdown(void) {
     g.small.release();
     g.trends.release();
     g.onepass.release();
+    g.pend_trend.release();
     g.cmS.release();
     g.cmT.release();
     g.cmG.release();
@@ -717,7 +735,19 @@ void sp_shutdown(void) {
 
 int sp_set_stream(void *hip_stream) {
     if (ensure_init()) return -1;
-    g.stream = (hipStream_t)hip_stream;
+    ApiLock lk;
+    hipStream_t ns = (hipStream_t)hip_stream;
+    if (ns != g.stream) {
+        // the library's scratch buffers are shared by all calls: work already queued on the old stream must finish
+        // before work on the new one may reuse them.  (The old stream may have been destroyed by its owner: errors of
+        // the record are dropped, there is nothing left to order against then.)
+        if (!g.ev_sw && hipEventCreateWithFlags(&g.ev_sw, hipEventDisableTiming) != hipSuccess) g.ev_sw = nullptr;
+        if (g.ev_sw) {
+            if (hipEventRecord(g.ev_sw, g.stream) == hipSuccess) (void)hipStreamWaitEvent(ns, g.ev_sw, 0);
+            (void)hipGetLastError();
+        }
+        g.stream = ns;
+    }
     return 0;
 }
 
@@ -764,7 +794,7 @@ int sp_device_info(int64_t out[4]) {
 int sp_mean(const void *x, int x_dtype, int64_t n, double out[2], int mem) {
     if (ensure_init()) return -1;
     if (n <= 0) return fail("sp_mean: n must be positive");
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const size_t esz = x_dtype == SP_DTYPE_C64 ? 8 : 4;
     const void *xd = x;
     if (!mem) {
@@ -788,7 +818,7 @@ int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int directio
     if (n < 1 || batch < 0) return fail("sp_fft_c2c: bad n/batch");
     if (direction != -1 && direction != 1) return fail("sp_fft_c2c: direction must be -1 or +1");
     if (batch == 0) return 0;
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const size_t bytes = sizeof(cf) * (size_t)n * (size_t)batch;
     const cf *din = (const cf *)in;
     cf *dout = (cf *)out;
@@ -817,7 +847,7 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         detrend = SP_DETREND_CONST;
         mean_re = mean_im = 0.0;
     }
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const bool lng = !wg_capable(nfft);          // segment longer than one workgroup transform: multi-kernel path
     Xf xf;
     if (!lng && get_xf(nfft, &xf)) return -1;
@@ -894,7 +924,7 @@ int sp_welch_accum(const void *x, int x_dtype, int64_t nsig, const float *win, i
                    int64_t nmean, double *sum_out, int mem) {
     if (ensure_init()) return -1;
     if (check_frames("sp_welch_accum", nsig, nfft, hop, nframes)) return -1;
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const bool cplx = x_dtype == SP_DTYPE_C64;
     const size_t esz = cplx ? 8 : 4;
     const void *xd = x;
@@ -918,7 +948,7 @@ int sp_welch_finish(const double *mean, int64_t frames_total, int sided, double 
     if (ensure_init()) return -1;
     if (sided < 1 || sided > 3) return fail("sp_welch_finish: bad sided");
     if (frames_total < 1) return fail("sp_welch_finish: frames_total must be positive");
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     if (!g_pend.valid) return fail("sp_welch_finish: no pending sp_welch_accum");
     const int nb = nbins_host(g_pend.nfft, sided);
     double *out_d = pxx_out;
@@ -944,7 +974,7 @@ int sp_welch_export(const void *x, int x_dtype, int64_t nsig, const float *win, 
                     int64_t nmean, double *state, int mem) {
     if (ensure_init()) return -1;
     if (check_frames("sp_welch_export", nsig, nfft, hop, nframes)) return -1;
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const bool cplx = x_dtype == SP_DTYPE_C64;
     const size_t esz = cplx ? 8 : 4;
     const void *xd = x;
@@ -975,7 +1005,7 @@ int sp_welch_apply(const double *state, const float *win, int nfft, int64_t fram
     if (ensure_init()) return -1;
     if (sided < 1 || sided > 3) return fail("sp_welch_apply: bad sided");
     if (frames_total < 1) return fail("sp_welch_apply: frames_total must be positive");
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
     if (xf.blue) return fail("sp_welch_apply: power-of-two nfft only");
@@ -1013,7 +1043,7 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         detrend = SP_DETREND_CONST;
         mean_x = mean_y = nullptr;
     }
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const bool lng = !wg_capable(nfft);
     Xf xf;
     if (!lng && get_xf(nfft, &xf)) return -1;
@@ -1148,7 +1178,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     if (check_frames(who, nsig, nfft, hop, nframes)) return -1;
     if (nch < 1 || x_ld < nsig) return fail("%s: bad nch / x_ld", who);
     if (detrend < 0 || detrend > 2) return fail("%s: detrend must be 0, 1 or 2", who);
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
     const int nb = nfft / 2 + 1;
@@ -1258,7 +1288,7 @@ int sp_csd_matrix_means(const float *x, int nch, int64_t nsig, int64_t x_ld, con
 int sp_channel_means(const float *x, int nch, int64_t nsig, int64_t x_ld, double *means_out, int mem) {
     if (ensure_init()) return -1;
     if (nch < 1 || nch > 512 || nsig < 1 || x_ld < nsig) return fail("sp_channel_means: need 1 <= nch <= 512, 1 <= nsig <= x_ld");
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const float *xd = x;
     if (!mem) {
         const size_t ib = sizeof(float) * (size_t)x_ld * (size_t)nch;
@@ -1290,7 +1320,7 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
         detrend = SP_DETREND_CONST;
         mean_re = mean_im = 0.0;
     }
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const bool lng = !wg_capable(nfft);
     Xf xf;
     if (!lng && get_xf(nfft, &xf)) return -1;
@@ -1363,7 +1393,7 @@ int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int 
         detrend = SP_DETREND_CONST;
         mean_re = mean_im = 0.0;
     }
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const bool lng = !wg_capable(nfft);
     Xf xf;
     if (!lng && get_xf(nfft, &xf)) return -1;
@@ -1428,7 +1458,7 @@ int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int 
 int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t batch, void *out, int mem) {
     if (ensure_init()) return -1;
     if (n_in < 1 || nfft < 2 || batch < 1 || x_ld < n_in) return fail("sp_hilbert: bad sizes");
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const float *xd = x;
     cf *od = (cf *)out;
     const size_t ibytes = sizeof(float) * (size_t)x_ld * (size_t)batch;
@@ -1473,7 +1503,7 @@ int sp_frame_sum(const void *x, int x_dtype, int64_t nsig, int nch, int64_t x_ld
     if (check_frames("sp_frame_sum", nsig, nfft, hop, nframes)) return -1;
     if (nch < 1 || nch > 65535 || x_ld < nsig) return fail("sp_frame_sum: bad nch / x_ld");
     if (detrend < 0 || detrend > 2) return fail("sp_frame_sum: detrend must be 0, 1 or 2");
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const bool cplx = x_dtype == SP_DTYPE_C64;
     const size_t esz = cplx ? 8 : 4;
     const void *xd = x;
@@ -1512,7 +1542,7 @@ int sp_spectral_filter(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft,
                        int mem) {
     if (ensure_init()) return -1;
     if (n_in < 1 || nfft < 2 || batch < 1 || x_ld < n_in || H == nullptr) return fail("sp_spectral_filter: bad sizes");
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const float *xd = x;
     cf *od = (cf *)out;
     const size_t ibytes = sizeof(float) * (size_t)x_ld * (size_t)batch;
@@ -1556,7 +1586,7 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
     const int64_t L = next_pow2(2 * n) < 2 ? 2 : next_pow2(2 * n);
     if (L > ((int64_t)1 << SP_MAX_BIG_LOG2))
         return fail("sp_xcorr: n=%lld needs a %lld-point transform; the limit is 2^%d", (long long)n, (long long)L, SP_MAX_BIG_LOG2);
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     const float *a = x1, *b = x2;
     float *od = co_out;
     const size_t ibytes = sizeof(float) * (size_t)n, obytes = sizeof(float) * (size_t)(2 * n - 1);
@@ -1606,7 +1636,7 @@ int sp_fftfilt(const float *h, int ntaps, const float *x, int64_t n, int nfft, f
     }
     if (!(is_pow2(nfft) && nfft >= 2 && nfft <= SP_MAX_WG_FFT) || nfft < 2 * (ntaps - 1) || nfft <= ntaps - 1)
         return fail("sp_fftfilt: nfft=%d must be a power of two with 2*(ntaps-1) <= nfft <= %d", nfft, SP_MAX_WG_FFT);
-    std::lock_guard<std::mutex> lk(g.mu);
+    ApiLock lk;
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
     // Hs = FFT(h zero-padded)/nfft, cached per (taps, nfft)

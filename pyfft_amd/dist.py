@@ -65,6 +65,43 @@ def welch_psd_sharded(x_local, win, plan, scale=1.0, sided=2, group=None, backen
     return apply(st if is_t else st.numpy(), win, plan.frames_total, sided, scale)
 
 
+class WelchPipeline(object):
+    """welch_psd_sharded with the collective of one step hidden behind the kernels of the next one.
+
+    The exchange is 5 nfft + 8 doubles (160 KiB at nfft = 4096): pure latency, ~5 % of a 2^28-sample step when it sits
+    between the accumulate kernel and the finish kernel.  `submit(x_local)` runs the export kernels of THIS step, starts
+    its all-reduce asynchronously (torch.distributed async_op: on RCCL the collective runs on the process group's own
+    stream, ordered after the export kernels) and then finishes the PREVIOUS step, whose all-reduce has had a whole
+    step to complete; it returns the previous step's PSD (None on the first call).  `flush()` finishes the last one.
+    K submits + one flush do exactly the work of K welch_psd_sharded calls."""
+
+    def __init__(self, win, plan, scale=1.0, sided=2, group=None, backend=None):
+        self.win, self.plan, self.scale, self.sided, self.group = win, plan, scale, sided, group
+        self.export, self.apply = backend if backend is not None else _device_backend()
+        self._pending = None
+
+    def _finish(self, pending):
+        import torch
+        st, work, is_t = pending
+        if work is not None:
+            work.wait()                  # RCCL: a stream-level wait; gloo: blocks the host until the sum has arrived
+        return self.apply(st if is_t else st.numpy(), self.win, self.plan.frames_total, self.sided, self.scale)
+
+    def submit(self, x_local):
+        import torch
+        import torch.distributed as dist
+        s = self.export(x_local, self.win, self.plan.hop, self.plan.frames, self.plan.own_samples)
+        is_t = isinstance(s, torch.Tensor)
+        st = s if is_t else torch.from_numpy(np.ascontiguousarray(s, dtype=np.float64))
+        work = dist.all_reduce(st, group=self.group, async_op=True) if self.plan.world > 1 else None
+        prev, self._pending = self._pending, (st, work, is_t)
+        return None if prev is None else self._finish(prev)
+
+    def flush(self):
+        prev, self._pending = self._pending, None
+        return None if prev is None else self._finish(prev)
+
+
 def welch_psd_sharded_two_step(x_local, win, plan, scale=1.0, sided=2, group=None):
     """The same result with the older split (sp_welch_accum / sp_welch_finish): all_reduce(2 doubles) of the sample sums,
     finish with the global mean, all_reduce(nbins doubles) of the finished shard spectra.  Two collectives; kept for the
@@ -85,12 +122,33 @@ def welch_psd_sharded_two_step(x_local, win, plan, scale=1.0, sided=2, group=Non
     return pt if isinstance(p, torch.Tensor) else pt.numpy()
 
 
-def csd_matrix_sharded(x_local, win, plan, scale=1.0, group=None, backend=None):
+def _hermitian_pack(g, dtype):
+    """upper triangle (i <= j) of G[k, i, j] as [nb, nch (nch + 1) / 2] in `dtype` (torch tensor in, torch tensor out)"""
+    import torch
+    nch = g.shape[-1]
+    iu = torch.triu_indices(nch, nch, device=g.device)
+    return g[:, iu[0], iu[1]].to(dtype).contiguous(), iu
+
+
+def _hermitian_unpack(tri, iu, nch, dtype):
+    import torch
+    nb = tri.shape[0]
+    g = torch.zeros((nb, nch, nch), dtype=dtype, device=tri.device)
+    t = tri.to(dtype)
+    g[:, iu[1], iu[0]] = torch.conj(t)
+    g[:, iu[0], iu[1]] = t                       # the diagonal from the un-conjugated copy
+    return g
+
+
+def csd_matrix_sharded(x_local, win, plan, scale=1.0, group=None, backend=None, compact=True):
     """Full CSD matrix (BASELINE cfg5) of a long multi-channel record from this rank's frame shard x_local[nch,
     plan.nsamples] (same ShardPlan as the PSD: contiguous frame ranges + halo).  Every channel is detrended with the
     mean of the WHOLE record: all_reduce(nch doubles) of the shard sample sums first, then each rank contracts its
-    frames and the accumulator -- the only large exchange, (nfft/2+1) x nch x nch complex128, 134 MB at cfg5 -- is
-    summed with one all_reduce.  `backend` = (means, matrix) callables; default: the HIP kernels."""
+    frames and the accumulator -- the only large exchange of the scope -- is summed with one all_reduce.
+    compact=True (default) sends only the Hermitian upper triangle in complex64: (nfft/2+1) nch (nch+1)/2 x 8 B, 34 MB at
+    cfg5 instead of the 134 MB of the full complex128 matrix (xGMI ring all-reduce is per-link bound, so the bytes are
+    the time); every shard's matrix is float32-accurate anyway and at most `world` such terms are added.
+    compact=False reduces the full complex128 matrix.  `backend` = (means, matrix) callables; default: the HIP kernels."""
     import torch
     import torch.distributed as dist
     if backend is None:
@@ -110,7 +168,11 @@ def csd_matrix_sharded(x_local, win, plan, scale=1.0, group=None, backend=None):
                   scale * float(plan.frames) / float(plan.frames_total))
     gt = g if isinstance(g, torch.Tensor) else torch.from_numpy(np.asarray(g, dtype=np.complex128))
     if plan.world > 1:
-        if gt.is_complex():
+        if compact and gt.is_complex() and gt.dim() == 3:
+            tri, iu = _hermitian_pack(gt, torch.complex64)
+            dist.all_reduce(torch.view_as_real(tri), group=group)
+            gt = _hermitian_unpack(tri, iu, gt.shape[-1], gt.dtype)
+        elif gt.is_complex():
             dist.all_reduce(torch.view_as_real(gt), group=group)
         else:
             dist.all_reduce(gt, group=group)
@@ -172,3 +234,63 @@ def cog_frames_sharded(x_local, win, plan, fs, fmin=0.0, fmax=None, mean_value=N
     dist.all_gather(parts, padded, group=group)
     out = torch.cat([parts[r][:base + (1 if r < extra else 0)] for r in range(world)])
     return out if isinstance(mine, torch.Tensor) else out.numpy()
+
+
+# ---- paths without a reduction: very long streams dealt out in pieces (north star: "very-long-stream overlap-save shard
+# ... segments across the 8 GPUs"; SURVEY 8e: "replicas + concatenation", no collective on the data path) ---------------
+SamplePlan = namedtuple("SamplePlan", "rank world ntaps total first last read_first nread")
+
+
+def sample_shard_plan(total_samples, ntaps, world, rank):
+    """Overlap-save FIR across ranks: rank r produces the outputs [first, last) of y = lfilter(h, 1, x) and READS the
+    inputs [read_first, read_first + nread) = its own samples plus the ntaps-1 samples before them (the filter's memory;
+    rank 0 has none: the stream starts at rest)."""
+    total_samples, ntaps = int(total_samples), int(ntaps)
+    if world > total_samples:
+        raise ValueError("more ranks than samples")
+    base, extra = divmod(total_samples, world)
+    first = rank * base + min(rank, extra)
+    last = first + base + (1 if rank < extra else 0)
+    rf = max(0, first - (ntaps - 1))
+    return SamplePlan(rank, world, ntaps, total_samples, first, last, rf, last - rf)
+
+
+def fftfilt_sharded(h, x_local, plan, gather=False, group=None, backend=None):
+    """This rank's piece y[plan.first:plan.last] of the causal FIR y = lfilter(h, 1, x) of one long stream, from
+    x_local = x[plan.read_first : plan.read_first + plan.nread] (own samples + halo).  No exchange on the data path: the
+    halo outputs are simply dropped.  gather=True all-gathers the pieces so that every rank holds the whole y
+    (4 bytes per sample -- only for tests and small streams).  `backend(h, x)` -> filtered x; default: engine.fir_filter."""
+    import torch
+    import torch.distributed as dist
+    if backend is None:
+        from . import engine as E
+        backend = lambda taps, x: E.fir_filter(taps, x)          # noqa: E731
+    y = backend(h, x_local)
+    own = y[plan.first - plan.read_first:]
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if world == 1 or not gather:
+        return own
+    t = own if isinstance(own, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(own))
+    base, extra = divmod(plan.total, plan.world)
+    width = base + (1 if extra else 0)
+    padded = torch.zeros(width, dtype=t.dtype, device=t.device)
+    padded[:t.numel()] = t
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    out = torch.cat([parts[r][:base + (1 if r < extra else 0)] for r in range(world)])
+    return out if isinstance(own, torch.Tensor) else out.numpy()
+
+
+def stft_sharded(x_local, win, plan, detrend=False, mean_value=None, sided=1, amp_scale=1.0, power=False, backend=None):
+    """This rank's frames [plan.first_frame, plan.first_frame + plan.frames) of the STFT of one long stream (same ShardPlan
+    as the PSD: contiguous frame ranges + halo).  Frames are independent: no collective; the spectrogram stays sharded
+    ([plan.frames, nbins] per rank, concatenation along the frame axis is the whole result).  A global-mean detrend needs
+    the mean of the whole stream: pass it as `mean_value`.  `backend(x, win, hop, frames, detrend, mean_value, sided,
+    amp_scale, power)` -> [frames, nbins]; default: engine.stft_frames."""
+    if backend is None:
+        from . import engine as E
+
+        def backend(x, w, hop, frames, d, mv, sd, amp, pw):
+            return E.stft_frames(x, w, hop, frames, detrend=d, sided=sd, amp_scale=amp, power=pw, mean_value=mv)[0]
+    return backend(x_local, win, plan.hop, plan.frames, bool(detrend) or mean_value is not None, mean_value, sided,
+                   amp_scale, power)

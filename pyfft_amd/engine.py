@@ -253,9 +253,17 @@ def welch_csd(x, y, win, hop, nframes, detrend=True, sided=SIDED_ONE, scale=1.0)
     if _is_torch(x):
         _bind_stream(x)
         xs = _torch_samples(x)
+        if not _is_torch(y):
+            raise TypeError("welch_csd: x is a device tensor, y must be one too")
         ys = _torch_samples(y)
         if ys.dim() == 1:
             ys = ys[None, :]
+        if ys.dtype != xs.dtype:
+            raise TypeError("welch_csd: x is %s but y is %s (both float32 or both complex64)" % (xs.dtype, ys.dtype))
+        if ys.device != xs.device:
+            raise ValueError("welch_csd: x and y live on different devices")
+        if xs.dim() != 1 or ys.dim() != 2 or ys.shape[1] < xs.numel():
+            raise ValueError("welch_csd: x[nsig] against y[nch, >= nsig]")
         nch, ld = ys.shape
         pxx = torch.empty(nb, dtype=torch.float64, device=xs.device)
         pyy = torch.empty((nch, nb), dtype=torch.float64, device=xs.device)
@@ -463,12 +471,20 @@ def xcorr_normalised(x1, x2):
     """co[2n-1] = correlate(x1-m1, x2-m2, 'full') / (n std1 std2), float32."""
     if _is_torch(x1):
         _bind_stream(x1)
+        if not _is_torch(x2) or x2.device != x1.device:
+            raise ValueError("xcorr: both signals must be tensors on the same device")
+        if x1.dim() != 1 or x2.shape != x1.shape:
+            raise ValueError("xcorr: two 1-D signals of equal length")
+        if x1.is_complex() or x2.is_complex():
+            raise TypeError("xcorr: real signals")
         a = x1.to(torch.float32).contiguous()
         b = x2.to(torch.float32).contiguous()
         n = a.numel()
         out = torch.empty(2 * n - 1, dtype=torch.float32, device=a.device)
         check(lib().sp_xcorr(ptr(a.data_ptr()), ptr(b.data_ptr()), n, ptr(out.data_ptr()), 1))
         return out
+    if np.iscomplexobj(x1) or np.iscomplexobj(x2):
+        raise TypeError("xcorr: real signals")
     a = np.ascontiguousarray(x1, dtype=np.float32)
     b = np.ascontiguousarray(x2, dtype=np.float32)
     if a.shape != b.shape or a.ndim != 1:

@@ -486,6 +486,10 @@ def _mlab_onesided(nfft, fs):
 
 def _mlab_spectra(x, y, fs, nfft, noverlap, detrend):
     """(Pxx, Pyy, Pxy, F) as matplotlib.mlab.psd / csd return them (y None: Pxx only)."""
+    if np.iscomplexobj(x) or (y is not None and np.iscomplexobj(y)):
+        # matplotlib.mlab switches to two-sided spectra for complex input; these wrappers band-select one-sided output
+        # and the reference only feeds them real signals -- refuse instead of silently dropping the imaginary part
+        raise TypeError("psd/csd/coh/coh2 take real signals (one-sided matplotlib.mlab spectra, fft_analysis.py:1060-1155)")
     x = np.ascontiguousarray(x, dtype=np.float32)
     step = nfft - int(noverlap)
     nseg = (x.size - int(noverlap)) // step

@@ -125,8 +125,11 @@ def _csd_worker(rank, world, port, nch, total, nfft, hop, out_dir):
     win = O.windows("Hanning", nwins=nfft)
     plan = shard_plan(total, nfft, hop, world, rank)
     x_local = x[:, plan.first_sample: plan.first_sample + plan.nsamples]
-    g = csd_matrix_sharded(x_local, win, plan, scale=1.0, backend=_oracle_csd_backend(nfft))
+    g = csd_matrix_sharded(x_local, win, plan, scale=1.0, backend=_oracle_csd_backend(nfft), compact=False)
     np.save(os.path.join(out_dir, "g%d.npy" % rank), g)
+    # default: only the Hermitian upper triangle travels, in complex64 (34 MB instead of 134 MB at cfg5)
+    gc = csd_matrix_sharded(x_local, win, plan, scale=1.0, backend=_oracle_csd_backend(nfft))
+    np.save(os.path.join(out_dir, "gc%d.npy" % rank), gc)
     dist.destroy_process_group()
 
 
@@ -142,6 +145,10 @@ def test_sharded_csd_matrix_matches_single_process(tmp_path, world):
     for r in range(world):
         g = np.load(os.path.join(str(tmp_path), "g%d.npy" % r))
         assert np.max(np.abs(g - ref)) <= 1e-10 * np.abs(ref).max()
+        gc = np.load(os.path.join(str(tmp_path), "gc%d.npy" % r))
+        assert gc.dtype == np.complex128 and gc.shape == ref.shape
+        assert np.max(np.abs(gc - ref)) <= 5e-7 * np.abs(ref).max()            # float32 exchange
+        assert np.max(np.abs(gc - np.conj(np.swapaxes(gc, 1, 2)))) <= 1e-7 * np.abs(ref).max()   # Hermitian by construction
 
 
 def _chan_worker(rank, world, port, nch, total, nfft, hop, out_dir):
@@ -229,3 +236,117 @@ def test_sharded_cog_frames_needs_no_exchange_and_gathers(tmp_path, world):
         np.testing.assert_allclose(d["full"], ref, rtol=1e-9, atol=1e-9)
         f0 = int(d["f0"])
         np.testing.assert_allclose(d["own"], ref[f0:f0 + len(d["own"])], rtol=1e-9, atol=1e-9)
+
+
+# ---- bench.py launches its own ranks when asked for N > 1 GPUs without a launcher ----------------------------------
+def test_bench_self_launch_dryrun():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset must start two ranks itself.  SP_BENCH_DRYRUN=1
+    replaces the GPU work with one gloo all-reduce so that the launch plumbing is exercised on a machine without GPUs."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["SP_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dryrun"] and d["n_gpus"] == 2 and d["rank_sum"] == 3.0 and d["steps"] == 3
+    # a failing child makes the parent exit non-zero
+    env["SP_BENCH_DRYRUN"] = "0"
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                         "--settle-steps", "0", "--cpu-log2n", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r2.returncode != 0
+
+
+# ---- the pipelined form: the collective of step i is consumed in step i+1 --------------------------------------------
+def _pipe_worker(rank, world, port, total, nfft, hop, out_dir):
+    from pyfft_amd.dist import WelchPipeline
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    win = O.windows("Hanning", nwins=nfft)
+    plan = shard_plan(total, nfft, hop, world, rank)
+    pipe = WelchPipeline(win, plan, scale=1.0, backend=_oracle_backend(win, nfft))
+    outs = []
+    for step in range(3):                                   # three different streams through the pipeline
+        rng = np.random.default_rng(500 + step)
+        stream = (rng.standard_normal(total) + 1j * rng.standard_normal(total) + (0.1 * step - 0.3j)).astype(np.complex64)
+        r = pipe.submit(stream[plan.first_sample: plan.first_sample + plan.nsamples])
+        assert (r is None) == (step == 0)
+        if r is not None:
+            outs.append(r)
+    outs.append(pipe.flush())
+    assert pipe.flush() is None
+    np.save(os.path.join(out_dir, "pp%d.npy" % rank), np.stack(outs))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_welch_pipeline_returns_each_step_one_submit_later(tmp_path, world):
+    total, nfft, hop = 20000, 512, 256
+    port = 36000 + os.getpid() % 2000 + world
+    mp.spawn(_pipe_worker, args=(world, port, total, nfft, hop, str(tmp_path)), nprocs=world, join=True)
+    win = O.windows("Hanning", nwins=nfft)
+    M = (total - nfft) // hop + 1
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), "pp%d.npy" % r))
+        assert got.shape[0] == 3
+        for step in range(3):
+            rng = np.random.default_rng(500 + step)
+            stream = (rng.standard_normal(total) + 1j * rng.standard_normal(total) + (0.1 * step - 0.3j)).astype(np.complex64)
+            ref = O.welch_psd_stream(stream, win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+            np.testing.assert_allclose(got[step], ref, rtol=1e-6, atol=1e-9 * ref.max())
+
+
+# ---- paths without a reduction: overlap-save FIR and STFT of one long stream dealt out to the ranks --------------------
+def _nored_worker(rank, world, port, total, ntaps, nfft, hop, out_dir):
+    from pyfft_amd.dist import sample_shard_plan, fftfilt_sharded, stft_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(4242)
+    x = rng.standard_normal(total)
+    h = rng.standard_normal(ntaps) / ntaps
+    sp = sample_shard_plan(total, ntaps, world, rank)
+    xl = x[sp.read_first: sp.read_first + sp.nread]
+    own = fftfilt_sharded(h, xl, sp, backend=O.fftfilt)
+    full = fftfilt_sharded(h, xl, sp, gather=True, backend=O.fftfilt)
+    fp = shard_plan(total, nfft, hop, world, rank)
+    win = O.windows("Hamming", nwins=nfft)
+
+    def stft_backend(xx, w, hp, frames, d, mv, sided, amp, power):       # oracle in place of engine.stft_frames
+        xx = np.asarray(xx, dtype=np.float64) - (mv if mv is not None else 0.0)
+        idx = (np.arange(frames) * hp)[:, None] + np.arange(len(w))[None, :]
+        return amp * np.fft.fft(w[None, :] * xx[idx], axis=-1)[:, :len(w) // 2]
+    S = stft_sharded(x[fp.first_sample: fp.first_sample + fp.nsamples], win, fp, mean_value=x.mean(), backend=stft_backend)
+    np.savez(os.path.join(out_dir, "n%d.npz" % rank), own=own, full=full, first=sp.first, last=sp.last, S=S, f0=fp.first_frame)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fir_and_stft_need_no_exchange(tmp_path, world):
+    total, ntaps, nfft, hop = 10007, 65, 256, 64
+    port = 38000 + os.getpid() % 2000 + world
+    mp.spawn(_nored_worker, args=(world, port, total, ntaps, nfft, hop, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(4242)
+    x = rng.standard_normal(total)
+    h = rng.standard_normal(ntaps) / ntaps
+    y = O.fftfilt(h, x)
+    win = O.windows("Hamming", nwins=nfft)
+    M = (total - nfft) // hop + 1
+    idx = (np.arange(M) * hop)[:, None] + np.arange(nfft)[None, :]
+    Sref = np.fft.fft(win[None, :] * (x - x.mean())[idx], axis=-1)[:, :nfft // 2]
+    covered = 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "n%d.npz" % r))
+        a, b = int(d["first"]), int(d["last"])
+        np.testing.assert_allclose(d["own"], y[a:b], rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(d["full"], y, rtol=1e-10, atol=1e-12)
+        covered += b - a
+        f0 = int(d["f0"])
+        np.testing.assert_allclose(d["S"], Sref[f0:f0 + d["S"].shape[0]], rtol=1e-10, atol=1e-10)
+    assert covered == total

@@ -179,3 +179,57 @@ def test_edge_shapes_of_cog_frame_sum_spectral_filter_deriv(P):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run() == []
+
+
+def test_table_cache_eviction_keeps_live_tables(P):
+    """with the device-table cache full, a miss inside a call must not free a table the same call already
+    holds (window cached as a plain table, FFT(window) missing), nor the tables of a pending sp_welch_accum."""
+    E = P.engine
+    rng = np.random.default_rng(99)
+    n, nfft, hop = 1 << 16, 4096, 2048
+    M = (n - nfft) // hop + 1
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n) + (0.5 - 0.25j)).astype(np.complex64)
+    win0 = O.windows("Hanning", nwins=nfft)
+    ref = O.welch_psd_stream(x, win0, nfft, hop, M, 1.0)
+    S2 = float(np.sum(win0 ** 2))
+    xs = x[:8 * nfft]
+
+    def churn(count, seed):
+        # `count` distinct windows, each cached as one plain table
+        for i in range(count):
+            w = np.hanning(nfft) * (1.0 + 1e-3 * (seed + i))
+            E.stft_frames(xs, w, nfft, 2, detrend=False, sided=E.SIDED_RAW)
+
+    churn(63, 0)
+    E.stft_frames(xs, win0, nfft, 2, detrend=False, sided=E.SIDED_RAW)      # win0 cached as a plain table: cache full (64)
+    got = E.welch_psd(x, win0, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0 / S2)   # hit on win0, miss on FFT(win0)
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-6 * ref.max())
+    # pending accumulate across 70 evicting calls
+    s = E.welch_accum(x, win0, hop, M)
+    churn(70, 1000)
+    mean = s / n
+    got2 = E.welch_finish(nfft, mean, M, sided=E.SIDED_TWO, scale=1.0 / S2)
+    np.testing.assert_allclose(got2, ref, rtol=2e-4, atol=1e-6 * ref.max())
+
+
+def test_device_tensor_argument_validation(P):
+    """the device-tensor (mem=1) paths check dtype / shape / device like the numpy paths do"""
+    import torch
+    E = P.engine
+    x = torch.zeros(4096, device="cuda")
+    yc = torch.zeros(4096, dtype=torch.complex64, device="cuda")
+    w = np.ones(256)
+    with pytest.raises(TypeError):
+        E.welch_csd(x, yc, w, 128, 4)                          # float32 x with complex64 y
+    with pytest.raises(TypeError):
+        E.welch_csd(x, np.zeros(4096, dtype=np.float32), w, 128, 4)
+    with pytest.raises(ValueError):
+        E.welch_csd(x, x[:100], w, 128, 4)                     # channel shorter than x
+    with pytest.raises(ValueError):
+        E.xcorr_normalised(x, x[:100])                         # would read past the end of x2
+    with pytest.raises(TypeError):
+        E.xcorr_normalised(yc, yc)
+    with pytest.raises(TypeError):
+        P.fft_analysis.psd(np.zeros(4096, dtype=np.complex128), 1.0)     # was: imaginary part silently dropped
+    pxx, pyy, pxy = E.welch_csd(x + 1, (x + 2)[None, :], w, 128, 4, detrend=False)
+    assert pxx.is_cuda and pyy.shape == (1, 128)

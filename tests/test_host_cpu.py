@@ -155,3 +155,15 @@ def test_named_window_catalogue_matches_reference():
     with pytest.raises(ValueError):
         W.exponential(8, center=2, sym=True)
     assert W.hanning is not None and set(W._win_equiv) >= {"hann", "tuk", "optimal", "dss"}
+
+
+def test_table_cache_policy(tmp_path):
+    """the device-table cache's eviction policy (pyfft_amd/csrc/table_cache.h) is host-only logic: built with g++ and run
+    here -- LRU, never an entry the current call obtained, never one a pending sp_welch_accum holds"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cache_policy_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "pyfft_amd", "csrc"),
+                    os.path.join(root, "tests", "cache_policy_test.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "cache policy ok" in out
