@@ -176,6 +176,13 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
  *      0 = choose). */
 int sp_fftfilt(const float *h, int ntaps, const float *x, int64_t n, int nfft, float *y, int mem);
 
+/* ---- F2 (build-defined): application of the second-order sections the reference only designs (notch_filter.py:19-241
+ *      iirnotch / iirpeak return (b, a) and nothing in the reference applies them; its scipy application sites for
+ *      other filters are filters.py:328 lfilter and :347 filtfilt).  y = scipy.signal.lfilter(b, a, x) for one biquad,
+ *      b[3], a[3] float64 HOST arrays (a[0] != 0), x and y float32 [n] (follow `mem`).  The recurrence is evaluated
+ *      exactly (float64 state, blocked scan of the affine state maps), not as a truncated FIR. */
+int sp_biquad(const double *b, const double *a, const float *x, int64_t n, float *y, int mem);
+
 /* ---- helper: mean of a float32 / complex64 vector in double (fft_analysis.py:2148 detrend) */
 int sp_mean(const void *x, int x_dtype, int64_t n, double out[2], int mem);
 

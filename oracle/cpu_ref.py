@@ -242,6 +242,37 @@ def pwelch_class(tvec, sigx, sigy=None, detrend_style=1, **kw):
     return out
 
 
+def crosscorr_class(r):
+    """fftanal.crosscorr_stft (fft_analysis.py:1880-1920) and fftanal.crosscorr (:1840-1878) on a pwelch_class() result:
+    correlations by inverse FFT of the per-segment / averaged spectra.  Everything the reference assigns before its
+    corrcoef line (which needs the never-set self.nch for 1-D signals and raises) -- pinned by
+    tests/golden/crosscorr_class.npz."""
+    nfft, onesided = r["nwins"], r["onesided"]
+
+    def back(P):
+        tmp = np.array(P, dtype=np.complex128)
+        if onesided:
+            tmp[..., 1:-1] *= 0.5                                # :1893 / :1852
+            if nfft % 2:
+                tmp[..., -1] *= 0.5
+            tmp = np.sqrt(nfft) * np.fft.irfft(tmp, n=nfft, axis=-1)
+        else:
+            tmp = np.sqrt(nfft) * np.fft.ifft(np.fft.ifftshift(tmp, axes=-1), n=nfft, axis=-1)
+        return tmp
+    out = {}
+    for name in ("Pxx", "Pyy", "Pxy"):
+        for suf in ("_seg", ""):
+            if name + suf in r:
+                tmp = back(r[name + suf])
+                if name == "Pxx":
+                    out["Ex" + suf] = tmp[..., 0].copy()
+                if name == "Pyy":
+                    out["Ey" + suf] = tmp[..., 0].copy()
+                out["R" + name[1:] + suf] = np.fft.fftshift(tmp, axes=-1)
+    out["lags"] = (np.arange(1, nfft + 1) - r["Nnyquist"]) / r["Fs"]
+    return out
+
+
 def welch_psd_stream(x, win, nfft, hop, nframes, Fs, detrend_style=1, chunk=4096):
     """Streaming two-sided (shifted) Welch PSD of the class path: identical arithmetic to
     fft_win -> Pstft -> averagewins (fft_analysis.py:2126-2203, :1946, :1980) without the [M,N]

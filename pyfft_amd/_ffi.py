@@ -50,6 +50,7 @@ SIGNATURES = {
     "sp_spectral_filter": (_i, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _i]),
     "sp_xcorr": (_i, [_vp, _vp, _i64, _vp, _i]),
     "sp_fftfilt": (_i, [_vp, _i, _vp, _i64, _i, _vp, _i]),
+    "sp_biquad": (_i, [_vp, _vp, _vp, _i64, _vp, _i]),
     "sp_mean": (_i, [_vp, _i, _i64, C.POINTER(_d), _i]),
 }
 

@@ -166,6 +166,59 @@ template <bool TWD> __device__ __forceinline__ void dft16s(cf (&x)[16], const Tw
 #undef SP_SWAP
 }
 
+// The same radix-16, but every finished output is handed to `store(k, value)` (k = natural-order output index) right
+// after the radix-4 butterfly that produced it, and the instruction scheduler may not move anything across the end of a
+// butterfly: the 16 LDS stores of a Stockham scatter are then spread over the last 64 VALU instructions of the pass
+// instead of forming one burst behind it (SP_EARLY_SCATTER; the burst is where the waves queue on the LDS pipe:
+// SQ_WAIT_INST_LDS was 16 % of the wave cycles of the metric kernel).
+template <bool TWD, class Store> __device__ __forceinline__ void dft16s_es(cf (&x)[16], const Tw16 &w, Store store) {
+    if constexpr (TWD) {
+#pragma unroll
+        for (int s = 1; s < 16; ++s) x[s] = rot_tan(x[s], w.f[Tw16::TAU + s - 1]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dft4s(x[b], x[b + 4], x[b + 8], x[b + 12], w.f[Tw16::RB + b], w.f[Tw16::RC + b], w.f[Tw16::RD + b]);
+    } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dft4<false>(x[b], x[b + 4], x[b + 8], x[b + 12]);
+    }
+    x[5] = rot_tan(x[5], SP_T16);
+    x[9] = mk(x[9].x + x[9].y, x[9].y - x[9].x);
+    x[13] = rot_tan(x[13], SP_T316);
+    x[6] = mk(x[6].x + x[6].y, x[6].y - x[6].x);
+    x[10] = mk(x[10].y, -x[10].x);
+    x[14] = mk(x[14].x - x[14].y, x[14].y + x[14].x);
+    x[7] = rot_tan(x[7], SP_T316);
+    x[11] = mk(x[11].x - x[11].y, x[11].y + x[11].x);
+    x[15] = rot_tan(x[15], SP_T16);
+    __builtin_amdgcn_sched_barrier(0);
+#define SP_ES_OUT(c)                                                                                                 \
+    store(c, x[4 * c]);                                                                                              \
+    store(c + 4, x[4 * c + 1]);                                                                                      \
+    store(c + 8, x[4 * c + 2]);                                                                                      \
+    store(c + 12, x[4 * c + 3]);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (TWD) {
+        dft4s(x[0], x[1], x[2], x[3], w.f[Tw16::S1 + 0], w.f[Tw16::S2 + 0], w.f[Tw16::S3 + 0]);
+        SP_ES_OUT(0)
+        dft4s(x[4], x[5], x[6], x[7], w.f[Tw16::S1 + 1], w.f[Tw16::S2 + 1], w.f[Tw16::S3 + 1]);
+        SP_ES_OUT(1)
+        dft4s(x[8], x[9], x[10], x[11], w.f[Tw16::S1 + 2], w.f[Tw16::S2 + 2], w.f[Tw16::S3 + 2]);
+        SP_ES_OUT(2)
+        dft4s(x[12], x[13], x[14], x[15], w.f[Tw16::S1 + 3], w.f[Tw16::S2 + 3], w.f[Tw16::S3 + 3]);
+        SP_ES_OUT(3)
+    } else {
+        dft4<false>(x[0], x[1], x[2], x[3]);
+        SP_ES_OUT(0)
+        dft4s(x[4], x[5], x[6], x[7], SP_C16, SP_C8, SP_S16 / SP_C16);
+        SP_ES_OUT(1)
+        dft4s(x[8], x[9], x[10], x[11], SP_C8, 1.f, -1.f);
+        SP_ES_OUT(2)
+        dft4s(x[12], x[13], x[14], x[15], SP_S16, -SP_C8, -SP_C16 / SP_S16);
+        SP_ES_OUT(3)
+    }
+#undef SP_ES_OUT
+}
+
 // ---- the same butterflies in packed fp32 (v_pk_fma_f32 / v_pk_add_f32), SP_PACKED=1 ---------------------------------
 // A complex value is one 64-bit register pair and every butterfly line is ONE packed instruction; the swap of re/im,
 // the broadcast of a real scale out of a register pair and the signs ride in the op_sel / neg modifiers (inline asm:
@@ -341,6 +394,27 @@ __device__ __forceinline__ void make_tw16(Tw16 &w, const cf (&wv)[15]) {
 #ifndef SP_ABLATE
 #define SP_ABLATE 0
 #endif
+// SP_READ_B64=1: the unit-stride gathers are issued as single ds_read_b64 (volatile LDS loads, which hipcc does not merge
+// into ds_read2_b64): 2 LDS cycles per 8 bytes per wave instead of 8 per 16 (MI355X_MICROARCH.md, LDS table); the first
+// exchange image then takes row pitch T+2 (32-lane groups over 64 banks) instead of T+1
+#ifndef SP_READ_B64
+#define SP_READ_B64 0
+#endif
+// SP_EARLY_SCATTER=1 (callers with two exchange images only): see dft16s_es
+#ifndef SP_EARLY_SCATTER
+#define SP_EARLY_SCATTER 0
+#endif
+typedef float sp_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf lds_load_single(const cf *p) {
+#if SP_READ_B64
+    // explicit LDS address space: a volatile access through a generic pointer is not narrowed to ds_read by hipcc
+    typedef const volatile __attribute__((address_space(3))) sp_f2v *lds_cvp;
+    const sp_f2v r = *(lds_cvp)(p);
+    return mk(r.x, r.y);
+#else
+    return *p;
+#endif
+}
 template <int RDX, bool INV> __device__ __forceinline__ void dftR(cf (&x)[RDX]) {
     if constexpr (RDX == 2) dft2<INV>(x[0], x[1]);
     else if constexpr (RDX == 4) dft4<INV>(x[0], x[1], x[2], x[3]);
@@ -368,7 +442,7 @@ template <int N> struct FftPlan {
     // bank = dword mod 32): lane stride must be == 2 dwords mod 32 -> pitch == 1 mod 16.  (T+2 would suit plain
     // ds_read_b64 -- 32-lane groups, 64 banks -- and costs a 2-way conflict on every read2: measured 256 LDS
     // conflict cycles per 4096-point frame.)
-    static constexpr int PITCH1 = T + 1;
+    static constexpr int PITCH1 = SP_READ_B64 ? T + 2 : T + 1;
     static constexpr int LDS_ELEMS = NP > 1 ? (R * PITCH1 > N ? R * PITCH1 : N) : 0;
 };
 
@@ -479,10 +553,10 @@ template <int N> struct WgFft {
             // i = tid + T*t  ->  (i%16)*PITCH1 + i/16 = (tid%16)*PITCH1 + tid/16 + (T/16)*t
             const int b = (tid % 16) * PL::PITCH1 + tid / 16;
 #pragma unroll
-            for (int t = 0; t < R; ++t) v[t] = lds[b + (T / 16) * t];
+            for (int t = 0; t < R; ++t) v[t] = lds_load_single(&lds[b + (T / 16) * t]);
         } else {
 #pragma unroll
-            for (int t = 0; t < R; ++t) v[t] = lds[phys<P>(tid + T * t)];
+            for (int t = 0; t < R; ++t) v[t] = lds_load_single(&lds[phys<P>(tid + T * t)]);
         }
     }
 
@@ -492,9 +566,25 @@ template <int N> struct WgFft {
         pass<0, SINGLE>(v, lds0, lds1, tid);
     }
 
+    // butterflies of pass P with the Stockham scatter folded in (radix 16, one butterfly per thread, scalar form)
+    template <int P> __device__ __forceinline__ void bfly_scatter(cf (&v)[R], cf *lds, int tid) const {
+        constexpr int NS = PL::ns(P);
+        const int base = (tid / NS) * (NS * 16) + (tid % NS);
+        auto store = [&](int k, cf val) __attribute__((always_inline)) { lds[phys<P>(base + k * NS)] = val; };
+        if constexpr (P > 0) dft16s_es<true>(v, t16[P - 1], store);
+        else dft16s_es<false>(v, t16[0], store);
+    }
+
     template <int P, bool SINGLE> __device__ __forceinline__ void pass(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
         constexpr bool LAST = (P == NP - 1);
         cf *lds = (P & 1) ? lds1 : lds0;
+        if constexpr (SP_EARLY_SCATTER && !SP_PACKED && !SP_ABLATE && !SINGLE && !LAST && PL::radix(P) == 16 && R == 16) {
+            bfly_scatter<P>(v, lds, tid);
+            __syncthreads();
+            gather<P>(v, lds, tid);
+            pass<P + 1, SINGLE>(v, lds0, lds1, tid);
+            return;
+        }
         if constexpr (!LAST && SINGLE && !(SP_ABLATE & 2)) __syncthreads();   // previous readers of this image are done
         bfly<P>(v, tid);
         if constexpr (!LAST && (SP_ABLATE & 2)) {

@@ -169,6 +169,10 @@ int launch_long_stft_out(LaunchCtx c, const cf *S, int64_t m, int nfft, int side
                          int64_t f0, int nb);
 int launch_long_cog(LaunchCtx c, const cf *S, int64_t m, int nfft, int klo, int khi, cf *acc, int64_t f0);
 
+// exact second-order IIR section (k_iir.hip)
+int64_t biquad_tiles(int64_t n);
+int launch_biquad(LaunchCtx c, const double *b, const double *a, const float *x, int64_t n, float *y, double *work);
+
 // dispatch over the transform: MACRO(XTYPE) with XTYPE = XfPow2<L> or XfBlue<L>
 #define SP_CASE_P(Lv, MACRO) case Lv: { MACRO(XfPow2<Lv>) } break;
 #define SP_CASE_B(Lv, MACRO) case Lv: { MACRO(XfBlue<Lv>) } break;

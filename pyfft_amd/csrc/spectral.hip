@@ -17,7 +17,7 @@
 
 using namespace sp;
 
-#define SP_VERSION 101
+#define SP_VERSION 102
 #define SP_MAX_WG_FFT 8192
 #define SP_MAX_BIG_LOG2 26          /* longest multi-pass power-of-two transform: 2^26 points (512 MiB per buffer) */
 
@@ -1620,6 +1620,29 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
     }
     if (!mem) {
         HIPCHK(hipMemcpyAsync(co_out, od, obytes, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
+}
+
+int sp_biquad(const double *b, const double *a, const float *x, int64_t n, float *y, int mem) {
+    if (ensure_init()) return -1;
+    if (n < 1 || b == nullptr || a == nullptr) return fail("sp_biquad: bad arguments");
+    if (a[0] == 0.0) return fail("sp_biquad: a[0] must not be zero");
+    ApiLock lk;
+    const float *xd = x;
+    float *yd = y;
+    const size_t bytes = sizeof(float) * (size_t)n;
+    if (!mem) {
+        if (g.in0.ensure(bytes) || g.out0.ensure(bytes)) return -1;
+        HIPCHK(hipMemcpyAsync(g.in0.p, x, bytes, hipMemcpyHostToDevice, g.stream));
+        xd = (const float *)g.in0.p;
+        yd = (float *)g.out0.p;
+    }
+    if (g.work.ensure(sizeof(double) * 4 * (size_t)biquad_tiles(n) + 64)) return -1;
+    LAUNCHCHK(launch_biquad(lc(), b, a, xd, n, yd, (double *)g.work.p));
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(y, yd, bytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
     }
     return 0;

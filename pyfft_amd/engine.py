@@ -511,3 +511,32 @@ def fir_filter(h, x, nfft=0):
     _ffi.init()
     check(lib().sp_fftfilt(ptr(taps), taps.size, ptr(xs), xs.size, int(nfft), ptr(out), 0))
     return out
+
+
+# ------------------------------------------------------------------------------------------ F2
+def biquad_filter(b, a, x):
+    """y = scipy.signal.lfilter(b, a, x) for one second-order section (b[3], a[3]), float32 samples, evaluated exactly
+    on the GPU (float64 recurrence, blocked scan of the state maps; include/spectral.h: sp_biquad)."""
+    bb = np.ascontiguousarray(b, dtype=np.float64).ravel()
+    aa = np.ascontiguousarray(a, dtype=np.float64).ravel()
+    if bb.size > 3 or aa.size > 3 or aa.size < 1 or bb.size < 1:
+        raise ValueError("biquad_filter: b and a hold at most 3 coefficients")
+    bb = np.concatenate([bb, np.zeros(3 - bb.size)])
+    aa = np.concatenate([aa, np.zeros(3 - aa.size)])
+    if aa[0] == 0.0:
+        raise ValueError("biquad_filter: a[0] must not be zero")
+    if _is_torch(x):
+        _bind_stream(x)
+        if x.is_complex() or x.dim() != 1:
+            raise TypeError("biquad_filter: one real 1-D signal")
+        xs = x.to(torch.float32).contiguous()
+        out = torch.empty_like(xs)
+        check(lib().sp_biquad(ptr(bb), ptr(aa), ptr(xs.data_ptr()), xs.numel(), ptr(out.data_ptr()), 1))
+        return out
+    if np.iscomplexobj(x) or np.ndim(x) != 1:
+        raise TypeError("biquad_filter: one real 1-D signal")
+    xs = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(xs)
+    _ffi.init()
+    check(lib().sp_biquad(ptr(bb), ptr(aa), ptr(xs), xs.size, ptr(out), 0))
+    return out

@@ -1,6 +1,8 @@
 """Second-order IIR notch / peak design (reference: notch_filter.py:19-241, Orfanidis 11.3.x) and its
 application.  The design is ten host flops and returns (b, a) like the reference; the reference never applies
-the filter -- `apply_notch` does, as a truncated-impulse-response FIR through the GPU overlap-save kernel."""
+the filter -- `apply_notch` does: by default the biquad recurrence itself, evaluated exactly on the GPU (sp_biquad:
+float64 state, blocked scan), or on request as a truncated-impulse-response FIR through the overlap-save kernel, with
+the truncation error bounded from the pole radius."""
 import numpy as np
 
 from . import engine as _E
@@ -49,8 +51,42 @@ def impulse_response(b, a, ntaps):
     return h
 
 
-def apply_notch(x, w0, Q, ntaps=513, ftype="notch", nfft=0):
-    """Filter x with the designed notch/peak biquad realised as an ntaps FIR (GPU overlap-save).  The truncation
-    error against the exact recursion is bounded by the tail of the impulse response (|pole|^ntaps)."""
+def pole_radius(a):
+    """largest pole magnitude of 1/A(z), a = [a0, a1, a2]"""
+    r = np.roots(np.asarray(a, dtype=np.float64))
+    return float(np.max(np.abs(r))) if r.size else 0.0
+
+
+def fir_taps_for(a, tol=1e-6, limit=4096):
+    """taps needed so that the dropped tail of the biquad's impulse response is below `tol` of its start: the tail decays
+    like |p|^n, so n >= log(tol) / log|p|.  Raises when that exceeds `limit` (the overlap-save kernel takes
+    2 (ntaps - 1) <= 8192): such a notch is what the exact recurrence (apply_notch's default) is for."""
+    r = pole_radius(a)
+    if r >= 1.0:
+        raise ValueError("unstable section (pole radius %.6f): no FIR truncation exists" % r)
+    n = 3 if r == 0.0 else int(np.ceil(np.log(tol) / np.log(r))) + 2
+    if n > limit:
+        raise ValueError("the impulse response decays like %.6f^n: %d taps are needed for a tail below %g, more than the "
+                         "FIR kernel's %d -- use the exact recurrence (ntaps=None)" % (r, n, tol, limit))
+    return max(n, 3)
+
+
+def apply_notch(x, w0, Q, ntaps=None, ftype="notch", nfft=0, tol=1e-6):
+    """Filter x with the designed notch/peak biquad: y = lfilter(b, a, x) (float32 samples).
+    ntaps=None (default): the recurrence itself, exact, on the GPU (engine.biquad_filter).
+    ntaps='auto' or an integer: the biquad as an ntaps-tap FIR through the overlap-save kernel; 'auto' sizes the taps so
+    that the dropped tail of the impulse response (|pole|^ntaps) stays below `tol`, an explicit count whose tail exceeds
+    `tol` raises ValueError instead of returning a silently different filter (w0=0.01, Q=30: |p|^513 = 0.77)."""
     b, a = _design_notch_peak_filter(w0, Q, ftype)
+    if ntaps is None:
+        return _E.biquad_filter(b, a, x)
+    if ntaps == "auto":
+        ntaps = fir_taps_for(a, tol)
+    else:
+        ntaps = int(ntaps)
+        tail = pole_radius(a) ** ntaps
+        if tail > tol:
+            raise ValueError("a %d-tap FIR drops an impulse-response tail of relative size %.3g (pole radius %.6f) > tol=%g; "
+                             "use ntaps=None (exact recurrence), ntaps='auto', or pass a larger tol on purpose"
+                             % (ntaps, tail, pole_radius(a), tol))
     return _E.fir_filter(impulse_response(b, a, ntaps), x, nfft=nfft)

@@ -51,18 +51,27 @@ def test_fft_pwelch_golden(P, tag):
         np.testing.assert_allclose(getattr(info, k), g["info_" + k], rtol=1e-12)
     np.testing.assert_allclose(freq, g["freq"], rtol=1e-12, atol=1e-12)
     assert Pxx.dtype == np.complex128 and Pxy.dtype == np.complex128
-    # Welch bins: rtol 2e-4 + atol 1e-6*max  (the noise-free self-test signals have > 200 dB of dynamic range in
-    # float64; float32 input quantisation sets the floor there -> atol relative to the peak)
+    # Welch bins: rtol 2e-4 + atol 1e-6*max (the noise-free self-test signals have > 200 dB of dynamic range
+    # in float64; float32 input quantisation sets the floor there -> atol relative to the peak)
     for name, got in (("Pxx", Pxx), ("Pyy", Pyy), ("Pxy", Pxy)):
         ref = g[name]
-        np.testing.assert_allclose(got, ref, rtol=3e-4, atol=2e-6 * np.max(np.abs(ref)), err_msg=name)
-    if tag in ("pwelch_cfg1", "pwelch_reflect", "pwelch_2ch_twosided"):
-        close_rel(Cxy, g["Cxy"], 2e-3, "Cxy")
-        for k in ("Lxx", "Lyy", "Lxy", "Rxx", "Ryy", "Rxy", "corrcoef", "lags", "varPxx", "Ex", "Ey"):
-            close_rel(np.atleast_1d(getattr(info, k)), g["info_" + k], 2e-3, k)
-        # phase where the coherence is significant
-        m = np.abs(g["Cxy"]) > 0.5
-        assert np.max(np.abs(np.angle(np.exp(1j * (phi[m] - g["phi_xy"][m]))))) < 2e-3
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-6 * np.max(np.abs(ref)), err_msg=name)
+    # epilogue (fft_analysis.py:489-648), every tag.  Quantities that are ratios of spectra (coherence, phase, corrcoef)
+    # are compared where the spectra stand above the float32 floor (1e-5 of their peak): the two self-test inputs are
+    # noise-free, their off-harmonic bins are rounding noise over rounding noise in the float64 reference itself.
+    nb = np.asarray(g["Pxx"]).shape[0]
+    pxx_r = np.abs(np.asarray(g["Pxx"])).reshape(nb, -1)
+    pyy_r = np.abs(np.asarray(g["Pyy"])).reshape(nb, -1)
+    solid = (pxx_r > 1e-5 * pxx_r.max()) & (pyy_r > 1e-5 * pyy_r.max())
+    cg, cr = np.asarray(Cxy).reshape(nb, -1), np.asarray(g["Cxy"]).reshape(nb, -1)
+    assert np.max(np.abs(cg - cr)[solid]) <= 2e-3, "Cxy"
+    m = solid & (np.abs(cr) > 0.5)
+    pg, pr = np.asarray(phi).reshape(nb, -1), np.asarray(g["phi_xy"]).reshape(nb, -1)
+    assert np.max(np.abs(np.angle(np.exp(1j * (pg[m] - pr[m]))))) < 2e-3, "phi_xy"
+    for k in ("Lxx", "Lyy", "Lxy", "Rxx", "Ryy", "Rxy", "lags", "varPxx", "Ex", "Ey"):
+        close_rel(np.atleast_1d(getattr(info, k)), g["info_" + k], 2e-3, k)
+    cc_r = np.asarray(g["info_corrcoef"])
+    close_rel(np.atleast_1d(info.corrcoef), cc_r, 2e-3, "corrcoef")
 
 
 def test_fft_pwelch_segments(P):
@@ -111,7 +120,7 @@ def test_fftanal_class_real_xy(P, wname):
     ft.pwelch()
     assert ft.onesided and ft.nwins == int(g["nwins"]) and ft.Navr == int(g["Navr"])
     for k in ("Pxx", "Pyy", "Pxy"):
-        np.testing.assert_allclose(getattr(ft, k), g[k], rtol=3e-4, atol=2e-6 * np.abs(g[k]).max(), err_msg=k)
+        np.testing.assert_allclose(getattr(ft, k), g[k], rtol=2e-4, atol=1e-6 * np.abs(g[k]).max(), err_msg=k)
     close_rel(ft.Xseg[:3], g["Xseg_head"], 1e-4, "Xseg")
     close_rel(ft.Yseg[:3], g["Yseg_head"], 1e-4, "Yseg")
     close_rel(ft.Lxx_seg[:2], g["Lxx_seg_head"], 1e-4, "Lxx_seg")
@@ -130,7 +139,7 @@ def test_stft_dropin(P):
     assert np.max(np.abs(st.Xseg[:3] - g["Xseg_head"])) <= 1e-4 * sc
     assert np.max(np.abs(st.Xseg[M // 2:M // 2 + 2] - g["Xseg_mid"])) <= 1e-4 * sc
     assert np.max(np.abs(st.Xseg[-2:] - g["Xseg_tail"])) <= 1e-4 * sc
-    np.testing.assert_allclose(st.Pxx, g["Pxx"], rtol=3e-4, atol=1e-6 * np.abs(g["Pxx"]).max())
+    np.testing.assert_allclose(st.Pxx, g["Pxx"], rtol=2e-4, atol=1e-6 * np.abs(g["Pxx"]).max())
     g2 = load_golden("stft_tuple_n256")
     twin, freq, Xseg = P.stft(g2["t"], g2["x"], tper=256.5, returnclass=False, windowfunction="Hamming")
     np.testing.assert_allclose(twin, g2["twin"], rtol=1e-12)
@@ -146,11 +155,11 @@ def test_specgram_dropin(P):
     np.testing.assert_allclose(sp1, g["sp1"], rtol=2e-4, atol=1e-6 * g["sp1"].max())
     time2, f2, sp2 = P.specgram(g["t"], g["s"], wl=500, hanning=False, overlap=False)     # wl not a power of two
     np.testing.assert_allclose(time2, g["time2"], rtol=1e-12)
-    np.testing.assert_allclose(sp2, g["sp2"], rtol=3e-4, atol=1e-6 * g["sp2"].max())
+    np.testing.assert_allclose(sp2, g["sp2"], rtol=2e-4, atol=1e-6 * g["sp2"].max())
     # windowAverage: block mean of consecutive frames
     ta, fa, spa = P.specgram(g["t"], g["s"], wl=500, hanning=False, windowAverage=3)
     nA = g["sp2"].shape[1] // 3
-    np.testing.assert_allclose(spa, g["sp2"][:, :nA * 3].reshape(500, nA, 3).mean(axis=2), rtol=3e-4,
+    np.testing.assert_allclose(spa, g["sp2"][:, :nA * 3].reshape(500, nA, 3).mean(axis=2), rtol=2e-4,
                                atol=1e-6 * g["sp2"].max())
 
 
@@ -198,10 +207,32 @@ def test_fftfilt_and_notch(P):
     yn = P.apply_notch(x, 0.12, 5.0, ntaps=513)
     exact = ss.lfilter(b, a, x.astype(np.float64))
     close_rel(yn, exact, 2e-4, "notch vs exact recursion")
+    # default: the recurrence itself on the GPU (float64 state): float32 output rounding is all that differs
+    close_rel(P.apply_notch(x, 0.12, 5.0), exact, 2e-7, "exact notch")
+    close_rel(P.apply_notch(x, 0.12, 5.0, ntaps="auto"), exact, 1e-4, "auto-sized FIR notch")
     # the tone is gone: power at f = 0.06 drops by > 40 dB
     def tone_power(v):
         return np.abs(np.sum(v[4096:] * np.exp(-2j * np.pi * 0.06 * k[4096:]))) ** 2
     assert tone_power(yn) < 1e-4 * tone_power(x)
+    # a NARROW notch (w0 = 0.01, Q = 30 -> pole radius 0.99948, |p|^513 = 0.77): the 513-tap FIR is refused, the
+    # exact recurrence matches scipy.signal.lfilter on a float64 host recursion; ragged length (not a multiple of the tile)
+    for (w0, Q, ftype, nn) in [(0.01, 30.0, "notch", n - 4321), (0.01, 200.0, "notch", n), (0.3, 50.0, "peak", 100003),
+                               (0.5, 0.7, "notch", 777), (0.02, 30.0, "peak", 5)]:
+        bq, aq = (P.iirnotch if ftype == "notch" else P.iirpeak)(w0, Q)
+        xe = x[:nn]
+        ex = ss.lfilter(bq, aq, xe.astype(np.float64))
+        got = P.apply_notch(xe, w0, Q, ftype=ftype)
+        assert got.dtype == np.float32 and got.shape == xe.shape
+        close_rel(got, ex, 3e-7, "exact %s w0=%g Q=%g" % (ftype, w0, Q))
+    with pytest.raises(ValueError, match="tail"):
+        P.apply_notch(x, 0.01, 30.0, ntaps=513)
+    with pytest.raises(ValueError, match="exact recurrence"):
+        P.apply_notch(x, 0.01, 30.0, ntaps="auto")
+    # general second-order sections through the engine entry (a[0] != 1, missing trailing coefficients)
+    E = P.engine
+    close_rel(E.biquad_filter([0.5, 0.25], [2.0, -1.0, 0.4], x), ss.lfilter([0.5, 0.25], [2.0, -1.0, 0.4], x.astype(np.float64)), 3e-7, "biquad")
+    with pytest.raises(ValueError):
+        E.biquad_filter([1.0], [0.0, 1.0], x)
     # smooth() of the reference == np.convolve(w/sum, reflect-padded, 'valid')
     from pyfft_amd.filters import smooth
     s = rng.standard_normal(3000)
@@ -218,17 +249,17 @@ def test_mlab_wrappers_psd_csd_coh():
     x, y, fs = g["x"], g["y"], float(g["fs"])
     p, f = P.psd(x, fs)
     np.testing.assert_allclose(f, g["psd_f"], rtol=1e-12)
-    np.testing.assert_allclose(p, g["psd_p"], rtol=3e-4, atol=1e-6 * g["psd_p"].max())
+    np.testing.assert_allclose(p, g["psd_p"], rtol=2e-4, atol=1e-6 * g["psd_p"].max())
     p, f = P.psd(x, fs, nfft=500, fmin=20.0, fmax=300.0, detrend="mean", ov=0.5)
     np.testing.assert_allclose(f, g["psd2_f"], rtol=1e-12)
-    np.testing.assert_allclose(p, g["psd2_p"], rtol=3e-4, atol=1e-6 * g["psd2_p"].max())
+    np.testing.assert_allclose(p, g["psd2_p"], rtol=2e-4, atol=1e-6 * g["psd2_p"].max())
     p, f = P.csd(x, y, fs)
     np.testing.assert_allclose(f, g["csd_f"], rtol=1e-12)
     assert np.max(np.abs(p - g["csd_p"])) <= 3e-4 * np.abs(g["csd_p"]).max()
     p, f = P.csd(x, y, fs, nfft=1024, fmin=None, fmax=None, detrend="mean", ov=0.75)
     assert np.max(np.abs(p - g["csd2_p"])) <= 3e-4 * np.abs(g["csd2_p"]).max()
     p, f = P.psd(x, fs, nfft=1024, detrend="linear", ov=0.5)
-    np.testing.assert_allclose(p, g["psd3_p"], rtol=3e-4, atol=1e-6 * g["psd3_p"].max())
+    np.testing.assert_allclose(p, g["psd3_p"], rtol=2e-4, atol=1e-6 * g["psd3_p"].max())
     p, f = P.csd(x, y, fs, nfft=600, fmin=None, fmax=None, detrend="linear", ov=0.25)
     assert np.max(np.abs(p - g["csd3_p"])) <= 3e-4 * np.abs(g["csd3_p"]).max()
     c, f = P.coh(x, y, fs)
@@ -240,7 +271,36 @@ def test_mlab_wrappers_psd_csd_coh():
     ref = O.mlab_coh2_wrapper(x, y, fs)                      # parity unpinned: the reference's coh2 raises (float noverlap)
     np.testing.assert_allclose(r["f"], ref["f"], rtol=1e-12)
     np.testing.assert_allclose(r["coh"], ref["coh"], rtol=2e-3, atol=2e-4)
-    np.testing.assert_allclose(r["PS"], ref["PS"], rtol=3e-4, atol=1e-6 * ref["PS"].max())
+    np.testing.assert_allclose(r["PS"], ref["PS"], rtol=2e-4, atol=1e-6 * ref["PS"].max())
+
+
+@pytest.mark.parametrize("onesided", [True, False])
+def test_fftanal_crosscorr_against_reference_fixture(P, onesided):
+    """fftanal.crosscorr_stft / crosscorr (fft_analysis.py:1840-1920) against the fixture the reference produced
+    (tests/golden/make_golden_xcorr.py); inverse FFTs of length 1333 (not a power of two) on the device"""
+    g = load_golden("crosscorr_class")
+    rng = np.random.default_rng(int(g["seed"]))
+    n, fs = int(g["n"]), float(g["fs"])
+    t = np.arange(n) / fs
+    x = np.sin(2 * np.pi * 50 * t) + 0.3 * rng.standard_normal(n)
+    y = np.sin(2 * np.pi * 50 * t + 0.7) + 0.3 * rng.standard_normal(n)
+    tag = "one" if onesided else "two"
+    ft = P.fftanal(t, x, y, tbounds=[t[0], t[-1]], Navr=8, windowoverlap=0.5, windowfunction="hanning",
+                   onesided=onesided, plotit=False, verbose=False, segments=True)
+    ft.pwelch()
+    assert ft.nwins == int(g["nwins_" + tag]) and ft.Nnyquist == int(g["Nnyquist_" + tag])
+    ft.crosscorr_stft()
+    for k in ("Rxx_seg", "Ryy_seg", "Rxy_seg", "Ex_seg", "Ey_seg"):
+        close_rel(np.asarray(getattr(ft, k)), g[k + "_" + tag], 2e-4, k)
+    ft.crosscorr()
+    for k in ("Rxx", "Ryy", "Rxy"):
+        close_rel(np.asarray(getattr(ft, k)).ravel(), g[k + "_" + tag].ravel(), 2e-4, k)
+    close_rel(np.atleast_1d(ft.Ex).ravel(), g["Ex_" + tag].ravel(), 2e-4, "Ex")
+    # corrcoef[_seg]: the reference's own line raises (self.nch unset, fixture err_* = AttributeError); the drop-in
+    # evaluates the formula it states, Rxy / sqrt(Ex Ey)
+    assert str(g["err_stft_" + tag]) == "AttributeError"
+    ref_cc = g["Rxy_seg_" + tag] / np.sqrt(g["Ex_seg_" + tag] * g["Ey_seg_" + tag])[:, None]
+    close_rel(ft.corrcoef_seg, ref_cc, 5e-4, "corrcoef_seg")
 
 
 def test_fftanal_crosscorr_stft_and_getters():

@@ -140,6 +140,35 @@ def test_cfg4_fir_full_size(T, E):
     np.testing.assert_allclose(yd[3583: 3583 + ntaps + 1], both, rtol=0, atol=3e-7)
     y2 = E.fir_filter(h, 3.0 * x, nfft=4096)
     assert float((y2 - 3.0 * y).abs().max() / y.abs().max()) < 2e-6
+    del y2, y
+    # "+ notch_filter" of cfg4 at FULL size: the designed biquad (notch_filter.py:19-95) applied to the 2^28 samples.
+    # (a) the exact recurrence against scipy.signal.lfilter on the whole stream, chunked on the host with the filter state
+    # carried over (zi), compared on windows spread over the stream including tile seams (8192) and the very end;
+    # (b) the same notch as a 513-tap FIR (wide notch, tail 4e-9) against (a);  (c) linearity.
+    from pyfft_amd.notch_filter import iirnotch, impulse_response
+    k = T.arange(n, device="cuda", dtype=T.float64)
+    x = (x + 0.3 * T.sin(2 * np.pi * T.remainder(0.06 * k, 1.0)).to(T.float32))
+    del k
+    for (w0, Q) in ((0.12, 5.0), (0.01, 30.0)):
+        b, a = iirnotch(w0, Q)
+        yq = E.biquad_filter(b, a, x)
+        zi = np.zeros(2)
+        step = 1 << 24
+        worst = 0.0
+        for a0 in range(0, n, step):
+            seg = x[a0:a0 + step].cpu().numpy().astype(np.float64)
+            ref, zi = ss.lfilter(b, a, seg, zi=zi)
+            if a0 in (0, step, 7 * step, n - step):                 # compare whole 2^24-sample pieces at four places
+                got = yq[a0:a0 + step].cpu().numpy()
+                worst = max(worst, float(np.max(np.abs(got - ref)) / np.abs(ref).max()))
+        assert worst <= 5e-7, (w0, Q, worst)
+        if Q == 5.0:
+            yf = E.fir_filter(impulse_response(b, a, 513), x, nfft=4096)
+            assert float((yf - yq).abs().max() / yq.abs().max()) < 2e-5
+            del yf
+        y3 = E.biquad_filter(b, a, -2.0 * x)
+        assert float((y3 + 2.0 * yq).abs().max() / yq.abs().max()) < 1e-6
+        del y3, yq
 
 
 def test_cfg5_csd_matrix_full_size(T, E):

@@ -152,7 +152,7 @@ def test_welch_psd_arbitrary_length(E, nfft, hop):
     idx = (np.arange(M) * hop)[:, None] + np.arange(nfft)[None, :]
     P2 = (np.abs(np.fft.fft(win * xd[idx], axis=-1)) ** 2).mean(axis=0)
     got2 = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
-    np.testing.assert_allclose(got2, np.fft.fftshift(P2), rtol=3e-4, atol=2e-6 * P2.max())
+    np.testing.assert_allclose(got2, np.fft.fftshift(P2), rtol=2e-4, atol=1e-6 * P2.max())
     nny = (nfft + 1) // 2 if nfft % 2 else nfft // 2
     P1 = P2[:nny].copy()
     P1[1:-1] *= 2
@@ -160,7 +160,7 @@ def test_welch_psd_arbitrary_length(E, nfft, hop):
         P1[-1] *= 2
     got1 = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_ONE, scale=1.0)
     assert got1.shape == (nny,)
-    np.testing.assert_allclose(got1, P1, rtol=3e-4, atol=2e-6 * P1.max())
+    np.testing.assert_allclose(got1, P1, rtol=2e-4, atol=1e-6 * P1.max())
 
 
 def test_welch_linear_detrend(E):
@@ -363,7 +363,7 @@ def test_real_pair_packing_equals_plain_path(E):
         xd = x.astype(np.float64)
         idx = (np.arange(M) * hop)[:, None] + np.arange(nfft)[None, :]
         refp = (np.abs(np.fft.fft(win * xd[idx], axis=-1)) ** 2).T
-        np.testing.assert_allclose(Pa, refp, rtol=3e-4, atol=2e-6 * refp.max())
+        np.testing.assert_allclose(Pa, refp, rtol=2e-4, atol=1e-6 * refp.max())
 
 
 def test_welch_errors(E):
@@ -474,7 +474,7 @@ def test_stft_golden_f32(E):
     np.testing.assert_allclose(pseg / Fs / S2, g["Xpow"], rtol=1e-4)
     # mean |Xseg|^2 == Pxx
     P = (np.abs(Xseg.astype(np.complex128)) ** 2).mean(axis=0)
-    np.testing.assert_allclose(P, g["Pxx"].real, rtol=3e-4, atol=1e-6 * g["Pxx"].real.max())
+    np.testing.assert_allclose(P, g["Pxx"].real, rtol=2e-4, atol=1e-6 * g["Pxx"].real.max())
 
 
 def test_stft_twosided_complex_and_power_binmajor(E):

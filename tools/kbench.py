@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--real", action="store_true")
     ap.add_argument("--ov", type=float, default=0.5)
+    ap.add_argument("--check", action="store_true", help="parity of the first 2^20 samples against the CPU oracle first")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     n = 1 << a.log2n
@@ -35,6 +36,16 @@ def main():
     hop = int(round(nfft * (1 - a.ov)))
     M = (n - nfft) // hop + 1
     win = windows("Hanning", nwins=nfft, verbose=False)
+    if a.check:
+        from oracle import cpu_ref as O
+        nc = min(n, 1 << 20)
+        Mc = (nc - nfft) // hop + 1
+        xc = x[:nc].cpu().numpy()
+        for detrend in (True, False):
+            got = E.welch_psd(x[:nc], win, hop, Mc, detrend=detrend, sided=E.SIDED_TWO, scale=1.0 / float(np.sum(win ** 2))).cpu().numpy()
+            ref = O.welch_psd_stream(xc, win, nfft, hop, Mc, 1.0, detrend_style=1 if detrend else 0)
+            err = float(np.max(np.abs(got - ref) / (2e-4 * np.abs(ref) + 1e-6 * ref.max())))
+            print("parity detrend=%d: worst/tolerance %.4f %s" % (detrend, err, "ok" if err <= 1 else "FAIL"))
     E.profile_enable(True)
     for detrend in (True, False):
         ms = []
