@@ -14,6 +14,7 @@ from . import spectrogram, hilbert as _hilbert_mod, ccf as _ccf_mod, filters, no
 from .windows import windows            # noqa: F401
 from .fft_analysis import fft_pwelch, fftanal, Cxy_Cxy2, psd, csd, coh, coh2     # noqa: F401
 from .fft_analysis import detrend_none, detrend_mean, detrend_linear, unwrap_tol, fft_deriv   # noqa: F401  (__init__.py:22-23)
+from .fft_analysis import integratespectra, varcoh, varphi, mean_angle                       # noqa: F401  (fft_analysis.py:835, :1218-1376)
 from .spectrogram import specgram, stft                      # noqa: F401
 from .hilbert import hilbert, hilbert_1d                     # noqa: F401
 from .ccf import ccf                                         # noqa: F401

@@ -6,7 +6,7 @@ the correlation epilogue -- runs on the MI355X through libspectral.so in float32
 window tables and the O(nfft) epilogue algebra stay on the host in float64, as in the reference.
 
 Deliberately not carried over (outside the hot-path scope): plotting (`plotit` is accepted
-and ignored), Monte-Carlo uncertainty helpers, integratespectra/getNpeaks.
+and ignored), the Monte-Carlo uncertainty helpers (monticoh / montiphi), getNpeaks.
 """
 import numpy as np
 
@@ -112,6 +112,117 @@ def _ifft_cols(P, nfft, hermitian_half):
     else:
         out = _E.ifft(np.ascontiguousarray(P2.T)).T.astype(np.complex128)
     return out[:, 0] if vec else out
+
+
+# ------------------------------------------------------------------------------------------
+# uncertainty propagation and band integration (fft_analysis.py:835-937, :1218-1376): O(nfft) host algebra on the
+# averaged spectra, like the rest of the epilogue
+# ------------------------------------------------------------------------------------------
+def varcoh(Pxy, varPxy, Pxx, varPxx, Pyy, varPyy, meansquared=True):
+    """Coherence and its propagated variance (fft_analysis.py:1218-1262).  varPxy carries the variances of Re Pxy and
+    Im Pxy in its real and imaginary parts."""
+    ms, mc = np.imag(Pxy), np.real(Pxy)
+    vs, vc = np.imag(varPxy), np.real(varPxy)
+    prop = (vc * (2 * mc / (mc ** 2 + ms ** 2)) ** 2 + vs * (2 * ms / (mc ** 2 + ms ** 2)) ** 2
+            + varPxx * (1 / Pxx) ** 2 + varPyy * (1 / Pyy) ** 2)
+    if meansquared:
+        Coh = np.abs(Pxy * np.conj(Pxy)) / (np.abs(Pxx) * np.abs(Pyy))
+        return Coh, Coh ** 2 * prop
+    Coh = Pxy / np.sqrt(np.abs(Pxx) * np.abs(Pyy))              # complex coherence; the reference then takes its
+    varCoh = 0.25 * (Coh ** 2 * prop) / Coh                      # complex square root (:1253-1258)
+    return np.sqrt(Coh), varCoh
+
+
+def varphi(Pxy_real, Pxy_imag, varPxy_real, varPxy_imag, angle_range=np.pi):
+    """Cross-phase and its propagated variance (fft_analysis.py:1300-1330)."""
+    if angle_range > 0.5 * np.pi:
+        ph = np.arctan2(Pxy_imag, Pxy_real)
+    else:
+        ph = np.arctan(Pxy_imag / Pxy_real)
+    tangent = Pxy_imag / Pxy_real
+    vartang = (varPxy_imag + varPxy_real * tangent ** 2) / (Pxy_real ** 2)
+    return ph, vartang / (1 + tangent ** 2) ** 2
+
+
+def mean_angle(phi, vphi=None, dim=0, angle_range=0.5 * np.pi, vsyst=None):
+    """Average of phase angles through their cartesian components (fft_analysis.py:1334-1376)."""
+    if vphi is None:
+        vphi = np.zeros_like(phi)
+    if vsyst is None:
+        vsyst = np.zeros_like(phi)
+    nphi = np.size(phi, dim)
+    cp = np.exp(1.0j * phi)
+    cvar = vphi * np.abs(cp) ** 2
+    cvsy = vsyst * np.abs(cp) ** 2
+    ca, sa = np.real(cp), np.imag(cp)
+    mca, msa = np.nanmean(ca, axis=dim), np.nanmean(sa, axis=dim)
+    vca = np.nanvar(ca, axis=dim) + np.nansum(cvar, axis=dim) / nphi ** 2
+    vsa = np.nanvar(sa, axis=dim) + np.nansum(cvar, axis=dim) / nphi ** 2
+    vca += (np.nansum(np.sqrt(cvsy), axis=dim) / nphi) ** 2.0
+    vsa += (np.nansum(np.sqrt(cvsy), axis=dim) / nphi) ** 2.0
+    return varphi(Pxy_real=mca, Pxy_imag=msa, varPxy_real=vca, varPxy_imag=vsa, angle_range=angle_range)
+
+
+def reshapech(x):
+    """1-D spectra as one column (stand-in for pybaseutils.utils.reshapech, absent from the reference checkout)."""
+    x = np.asarray(x)
+    return x.reshape(-1, 1) if x.ndim == 1 else x
+
+
+def trapz_var(x, y, vx=None, vy=None, dim=0):
+    """Trapezoidal integral of y over x along `dim` and the variance it inherits from vy: sum_i w_i^2 vy_i with the
+    trapezoid weights w.  Stand-in for pybaseutils.utils.trapz_var, which the reference imports but does not contain:
+    PARITY UNPINNED at this boundary (the semantics its call sites imply, fft_analysis.py:891-902).
+    Returns [integral, variance, None, None] like the four-value call sites expect."""
+    x = np.asarray(x, dtype=np.float64)
+    y = np.asarray(y)
+    w = np.zeros_like(x)
+    if x.size > 1:
+        d = np.diff(x)
+        w[:-1] += 0.5 * d
+        w[1:] += 0.5 * d
+    shape = [1] * y.ndim
+    shape[dim] = x.size
+    ww = w.reshape(shape)
+    integ = np.sum(ww * y, axis=dim)
+    var = None if vy is None else np.sum(ww ** 2 * np.asarray(vy), axis=dim)
+    return [integ, var, None, None]
+
+
+def integratespectra(freq, Pxy, Pxx, Pyy, frange, varPxy=None, varPxx=None, varPyy=None):
+    """Integrate auto- and cross-power over the band frange = [f_lo, f_hi] and derive the band's coherence and cross-phase
+    with propagated variances (fft_analysis.py:835-937; HeatPulse_Funcs.py:498-530 runs it per harmonic and channel on
+    the output of fft_pwelch).  -> (Pxy_i, Pxx_i, Pyy_i, Cxy_i, ph_i, info).
+    The reference's defaults for the variances call the non-existent numpy.size_like (:876-878); zeros are used."""
+    freq = np.asarray(freq)
+    Pxy, Pxx, Pyy = reshapech(Pxy), reshapech(Pxx), reshapech(Pyy)
+    varPxy = np.zeros_like(Pxy) if varPxy is None else reshapech(varPxy)
+    varPxx = np.zeros_like(Pxx) if varPxx is None else reshapech(varPxx)
+    varPyy = np.zeros_like(Pyy) if varPyy is None else reshapech(varPyy)
+    inds = np.where((freq >= frange[0]) * (freq <= frange[1]))[0]
+    f = freq[inds]
+    Pxy_real, varPxy_real, _, _ = trapz_var(f, np.real(Pxy[inds, :]), None, np.real(varPxy[inds, :]), dim=0)
+    Pxy_imag, varPxy_imag, _, _ = trapz_var(f, np.imag(Pxy[inds, :]), None, np.imag(varPxy[inds, :]), dim=0)
+    Pxy_i = Pxy_real + 1j * Pxy_imag
+    varPxy_i = varPxy_real + 1j * varPxy_imag
+    Pxx_i, varPxx_i, _, _ = trapz_var(f, Pxx[inds, :], None, varPxx[inds, :], dim=0)
+    Pyy_i, varPyy_i, _, _ = trapz_var(f, Pyy[inds, :], None, varPyy[inds, :], dim=0)
+    meansquared = 0
+    Cxy_i, varCxy_i = varcoh(Pxy_i, varPxy_i, Pxx_i, varPxx_i, Pyy_i, varPyy_i, meansquared)
+    angle_range = np.pi
+    ph_i, varph_i = varphi(Pxy_real, Pxy_imag, varPxy_real, varPxy_imag, angle_range)
+    info = Struct()
+    info.frange = np.asarray([frange[0], frange[1]])
+    info.ifrange = inds
+    info.Pxy_i, info.varPxy_i = Pxy_i, varPxy_i
+    info.Pxx_i, info.varPxx_i = Pxx_i, varPxx_i
+    info.Pyy_i, info.varPyy_i = Pyy_i, varPyy_i
+    info.angle_range, info.ph_i, info.varph_i = angle_range, ph_i, varph_i
+    info.meansquared, info.Cxy_i, info.varCxy_i = meansquared, Cxy_i, varCxy_i
+    fw = np.dot(f.reshape(len(inds), 1), np.ones((1, np.size(Pxy, axis=1)), dtype=float))     # :931-934 (unit spacing)
+    _trapz = getattr(np, "trapezoid", None) or np.trapz
+    info.fweighted = _trapz(fw * np.abs(Pxy[inds, :])) / _trapz(np.abs(Pxy[inds, :]))
+    return Pxy_i, Pxx_i, Pyy_i, Cxy_i, ph_i, info
 
 
 # ------------------------------------------------------------------------------------------

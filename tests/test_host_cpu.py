@@ -167,3 +167,35 @@ def test_table_cache_policy(tmp_path):
                     os.path.join(root, "tests", "cache_policy_test.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
     assert "cache policy ok" in out
+
+
+def test_uncertainty_and_band_integration_match_reference():
+    """varcoh / varphi / mean_angle / integratespectra (fft_analysis.py:835-937, :1218-1376; the harmonic-band integration
+    of HeatPulse_Funcs.py:498-530): fixture produced by the reference's own functions (make_golden_integrate.py).
+    trapz_var / reshapech are absent from the reference checkout -> stated stand-ins, PARITY UNPINNED at that boundary."""
+    g = load_golden("integrate")
+    freq, Pxx, Pyy, Pxy = g["freq"], g["Pxx"], g["Pyy"], g["Pxy"]
+    vPxx, vPyy, vPxy = g["vPxx"], g["vPyy"], g["vPxy"]
+    nch = Pyy.shape[1]
+    ones = np.ones((1, nch))
+    for ms in (True, False):
+        Coh, vCoh = FA.varcoh(Pxy, vPxy, Pxx[:, None] * ones, vPxx[:, None] * ones, Pyy, vPyy, meansquared=ms)
+        np.testing.assert_allclose(Coh, g["coh_ms%d" % ms], rtol=1e-12)
+        np.testing.assert_allclose(vCoh, g["vcoh_ms%d" % ms], rtol=1e-12)
+    for ar, tag in ((np.pi, "pi"), (0.25 * np.pi, "qpi")):
+        ph, vph = FA.varphi(Pxy.real, Pxy.imag, vPxy.real, vPxy.imag, angle_range=ar)
+        np.testing.assert_allclose(ph, g["ph_" + tag], rtol=1e-12)
+        np.testing.assert_allclose(vph, g["vph_" + tag], rtol=1e-12)
+    phi = np.angle(Pxy)
+    mph, vmph = FA.mean_angle(phi, vphi=0.01 * np.ones_like(phi), dim=0, angle_range=np.pi, vsyst=0.001 * np.ones_like(phi))
+    np.testing.assert_allclose(mph, g["mean_phi"], rtol=1e-12)
+    np.testing.assert_allclose(vmph, g["var_mean_phi"], rtol=1e-12)
+    Pxy_i, Pxx_i, Pyy_i, Cxy_i, ph_i, info = pyfft_amd.integratespectra(freq, Pxy, Pxx, Pyy, list(g["frange"]), vPxy, vPxx, vPyy)
+    for got, key in ((Pxy_i, "Pxy_i"), (Pxx_i, "Pxx_i"), (Pyy_i, "Pyy_i"), (Cxy_i, "Cxy_i"), (ph_i, "ph_i"),
+                     (info.varPxy_i, "varPxy_i"), (info.varPxx_i, "varPxx_i"), (info.varPyy_i, "varPyy_i"),
+                     (info.varCxy_i, "varCxy_i"), (info.varph_i, "varph_i"), (info.fweighted, "fweighted")):
+        np.testing.assert_allclose(np.asarray(got).reshape(g[key].shape), g[key], rtol=1e-12, err_msg=key)
+    assert list(info.ifrange) == list(g["ifrange"])
+    # defaults: the reference's own default branch cannot run (numpy.size_like does not exist); zeros are used
+    r = pyfft_amd.integratespectra(freq, Pxy[:, 0], Pxx, Pyy[:, 0], list(g["frange"]))
+    np.testing.assert_allclose(np.asarray(r[0]).ravel()[0], g["Pxy_i"].ravel()[0], rtol=1e-12)
