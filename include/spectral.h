@@ -176,6 +176,18 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
  *      0 = choose). */
 int sp_fftfilt(const float *h, int ntaps, const float *x, int64_t n, int nfft, float *y, int mem);
 
+/* ---- A6 / N1: the fft_pwelch epilogue on device-resident averaged spectra (fft_analysis.py:489-648, Cxy_Cxy2 :1662-1688):
+ *      complex coherence, mean-squared coherence, cross-phase, linear amplitude spectra (:526-540), and the correlations
+ *      Rxx, Ryy, Rxy, iCxy = sqrt(nfft) ifft(spectrum) (one-sided input: [1:-1] halved, irfft semantics; two-sided:
+ *      ifftshift first), fftshifted (:544-597), corrcoef = Rxy / sqrt(Ex Ey).  Inputs as sp_welch_csd leaves them:
+ *      pxx[nb], pyy[nch][nb], pxy[nch][nb][2] float64.  `out` holds sp_csd_epilogue_doubles(nch, nb, nfft) float64:
+ *        cxy[nch][nb][2] | cxy2[nch][nb] | phi[nch][nb] | lxx[nb] | lyy[nch][nb] | lxy[nch][nb] |
+ *        rxx[nfft][2] | ryy[nch][nfft][2] | rxy[nch][nfft][2] | icxy[nch][nfft][2] | corrcoef[nch][nfft][2] | e[1+nch][2]
+ *      (e = the zero-lag values Ex, Ey_c; imaginary parts are zero for one-sided input). */
+int64_t sp_csd_epilogue_doubles(int nch, int nb, int nfft);
+int sp_csd_epilogue(const double *pxx, const double *pyy, const double *pxy, int nch, int nb, int nfft, int onesided, double enbw,
+                    double *out, int mem);
+
 /* ---- F2 (build-defined): application of the second-order sections the reference only designs (notch_filter.py:19-241
  *      iirnotch / iirpeak return (b, a) and nothing in the reference applies them; its scipy application sites for
  *      other filters are filters.py:328 lfilter and :347 filtfilt).  y = scipy.signal.lfilter(b, a, x) for one biquad,

@@ -51,6 +51,8 @@ SIGNATURES = {
     "sp_xcorr": (_i, [_vp, _vp, _i64, _vp, _i]),
     "sp_fftfilt": (_i, [_vp, _i, _vp, _i64, _i, _vp, _i]),
     "sp_biquad": (_i, [_vp, _vp, _vp, _i64, _vp, _i]),
+    "sp_csd_epilogue_doubles": (_i64, [_i, _i, _i]),
+    "sp_csd_epilogue": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _d, _vp, _i]),
     "sp_mean": (_i, [_vp, _i, _i64, C.POINTER(_d), _i]),
 }
 

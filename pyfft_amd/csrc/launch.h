@@ -173,6 +173,14 @@ int launch_long_cog(LaunchCtx c, const cf *S, int64_t m, int nfft, int klo, int 
 int64_t biquad_tiles(int64_t n);
 int launch_biquad(LaunchCtx c, const double *b, const double *a, const float *x, int64_t n, float *y, double *work);
 
+// fft_pwelch epilogue on device-resident spectra (k_epilogue.hip)
+int launch_epi_elem(LaunchCtx c, const double *pxx, const double *pyy, const double *pxy, int nch, int nb, int nfft, int onesided,
+                    double enbw, double *cxy, double *cxy2, double *phi, double *lxx, double *lyy, double *lxy);
+int launch_epi_spec(LaunchCtx c, const double *pxx, const double *pyy, const double *pxy, const double *cxy, int nch, int nb,
+                    int nfft, int onesided, cf *X);
+int launch_epi_corr(LaunchCtx c, const cf *X, int nch, int nfft, int onesided, double *rxx, double *ryy, double *rxy, double *icxy,
+                    double *ee, double *cc);
+
 // dispatch over the transform: MACRO(XTYPE) with XTYPE = XfPow2<L> or XfBlue<L>
 #define SP_CASE_P(Lv, MACRO) case Lv: { MACRO(XfPow2<Lv>) } break;
 #define SP_CASE_B(Lv, MACRO) case Lv: { MACRO(XfBlue<Lv>) } break;

@@ -1625,6 +1625,53 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
     return 0;
 }
 
+int sp_csd_epilogue(const double *pxx, const double *pyy, const double *pxy, int nch, int nb, int nfft, int onesided, double enbw,
+                    double *out, int mem) {
+    if (ensure_init()) return -1;
+    if (nch < 1 || nch > 20000 || nb < 1 || nfft < 2 || nb > nfft) return fail("sp_csd_epilogue: bad sizes");
+    if (onesided && nb != nbins_host(nfft, SP_SIDED_ONE)) return fail("sp_csd_epilogue: one-sided spectra hold %d bins for nfft=%d", nbins_host(nfft, SP_SIDED_ONE), nfft);
+    if (!onesided && nb != nfft) return fail("sp_csd_epilogue: two-sided spectra hold nfft bins");
+    ApiLock lk;
+    const size_t NB = (size_t)nb, NF = (size_t)nfft, C = (size_t)nch;
+    const size_t n_in = NB * (1 + 3 * C);                                  // pxx | pyy | pxy (complex)
+    const size_t n_out = sp_csd_epilogue_doubles(nch, nb, nfft);
+    const double *dxx = pxx, *dyy = pyy, *dxy = pxy;
+    double *od = out;
+    if (!mem) {
+        if (g.out0.ensure(sizeof(double) * (n_in + n_out))) return -1;
+        double *st = (double *)g.out0.p;
+        HIPCHK(hipMemcpyAsync(st, pxx, sizeof(double) * NB, hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(st + NB, pyy, sizeof(double) * NB * C, hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(st + NB * (1 + C), pxy, sizeof(double) * 2 * NB * C, hipMemcpyHostToDevice, g.stream));
+        dxx = st;
+        dyy = st + NB;
+        dxy = st + NB * (1 + C);
+        od = st + n_in;
+    }
+    // out layout (doubles): cxy[C][NB][2] | cxy2[C][NB] | phi[C][NB] | lxx[NB] | lyy[C][NB] | lxy[C][NB] |
+    //                       rxx[NF][2] | ryy[C][NF][2] | rxy[C][NF][2] | icxy[C][NF][2] | corrcoef[C][NF][2] | e[1+C][2]
+    double *cxy = od, *cxy2 = cxy + 2 * C * NB, *phi = cxy2 + C * NB, *lxx = phi + C * NB, *lyy = lxx + NB, *lxy = lyy + C * NB;
+    double *rxx = lxy + C * NB, *ryy = rxx + 2 * NF, *rxy = ryy + 2 * C * NF, *icxy = rxy + 2 * C * NF, *cc = icxy + 2 * C * NF;
+    double *ee = cc + 2 * C * NF;
+    LAUNCHCHK(launch_epi_elem(lc(), dxx, dyy, dxy, nch, nb, nfft, onesided, enbw, cxy, cxy2, phi, lxx, lyy, lxy));
+    const size_t nsig = 3 * C + 1;
+    if (g.bigA.ensure(sizeof(cf) * nsig * NF)) return -1;
+    cf *X = (cf *)g.bigA.p;
+    LAUNCHCHK(launch_epi_spec(lc(), dxx, dyy, dxy, cxy, nch, nb, nfft, onesided, X));
+    if (dev_fft_any(X, X, nfft, (int64_t)nsig, 1)) return -1;
+    LAUNCHCHK(launch_epi_corr(lc(), X, nch, nfft, onesided, rxx, ryy, rxy, icxy, ee, cc));
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(out, od, sizeof(double) * n_out, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    return 0;
+}
+
+int64_t sp_csd_epilogue_doubles(int nch, int nb, int nfft) {
+    const int64_t C = nch, NB = nb, NF = nfft;
+    return 2 * C * NB + C * NB + C * NB + NB + C * NB + C * NB + 2 * NF + 4 * 2 * C * NF + 2 * (1 + C);
+}
+
 int sp_biquad(const double *b, const double *a, const float *x, int64_t n, float *y, int mem) {
     if (ensure_init()) return -1;
     if (n < 1 || b == nullptr || a == nullptr) return fail("sp_biquad: bad arguments");

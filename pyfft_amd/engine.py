@@ -540,3 +540,62 @@ def biquad_filter(b, a, x):
     _ffi.init()
     check(lib().sp_biquad(ptr(bb), ptr(aa), ptr(xs), xs.size, ptr(out), 0))
     return out
+
+
+# ------------------------------------------------------------------------------------------ A6 / N1
+def csd_epilogue(pxx, pyy, pxy, nfft, onesided, enbw):
+    """The fft_pwelch epilogue (fft_analysis.py:489-648) on the averaged spectra, on the device: pxx[nb], pyy[nch, nb],
+    pxy[nch, nb] complex as welch_csd returns them (numpy, or torch tensors that stay on the GPU).  Returns a dict of
+    channel-major arrays: Cxy[nch, nb] complex, Cxy2, phi, Lyy, Lxy [nch, nb], Lxx[nb], and the fftshifted correlations
+    Rxx[nfft], Ryy / Rxy / iCxy / corrcoef [nch, nfft] (real for one-sided input, complex otherwise), Ex, Ey[nch]."""
+    nfft, onesided = int(nfft), bool(onesided)
+    dev = _is_torch(pxx)
+    if dev:
+        _bind_stream(pxx)
+        a = pxx.to(torch.float64).contiguous() if not pxx.is_complex() else pxx.real.to(torch.float64).contiguous()
+        b = (pyy if not pyy.is_complex() else pyy.real).to(torch.float64).contiguous()
+        c = pxy.to(torch.complex128).contiguous()
+        if b.dim() == 1:
+            b, c = b[None, :], c[None, :]
+        nch, nb = b.shape
+        n_out = int(lib().sp_csd_epilogue_doubles(nch, nb, nfft))
+        out = torch.empty(n_out, dtype=torch.float64, device=a.device)
+        check(lib().sp_csd_epilogue(ptr(a.data_ptr()), ptr(b.data_ptr()), ptr(c.data_ptr()), nch, nb, nfft, 1 if onesided else 0,
+                                    float(enbw), ptr(out.data_ptr()), 1))
+        cplx = torch.view_as_complex
+    else:
+        a = np.ascontiguousarray(np.real(pxx), dtype=np.float64)
+        b = np.ascontiguousarray(np.real(pyy), dtype=np.float64)
+        c = np.ascontiguousarray(pxy, dtype=np.complex128)
+        if b.ndim == 1:
+            b, c = b[None, :], c[None, :]
+        nch, nb = b.shape
+        _ffi.init()
+        n_out = int(lib().sp_csd_epilogue_doubles(nch, nb, nfft))
+        out = np.empty(n_out, dtype=np.float64)
+        check(lib().sp_csd_epilogue(ptr(a), ptr(b), ptr(c), nch, nb, nfft, 1 if onesided else 0, float(enbw), ptr(out), 0))
+        cplx = lambda v: v[..., 0] + 1j * v[..., 1]                     # noqa: E731
+    pos = [0]
+
+    def take(*shape):
+        n = 1
+        for d in shape:
+            n *= d
+        v = out[pos[0]:pos[0] + n].reshape(shape)
+        pos[0] += n
+        return v
+    r = {}
+    r["Cxy"] = cplx(take(nch, nb, 2))
+    r["Cxy2"] = take(nch, nb)
+    r["phi"] = take(nch, nb)
+    r["Lxx"] = take(nb)
+    r["Lyy"] = take(nch, nb)
+    r["Lxy"] = take(nch, nb)
+    corr = {"Rxx": take(nfft, 2), "Ryy": take(nch, nfft, 2), "Rxy": take(nch, nfft, 2), "iCxy": take(nch, nfft, 2),
+            "corrcoef": take(nch, nfft, 2)}
+    e = take(1 + nch, 2)
+    for k, v in corr.items():
+        r[k] = v[..., 0] if onesided else cplx(v)
+    r["Ex"] = e[0, 0] if onesided else cplx(e[0])
+    r["Ey"] = e[1:, 0] if onesided else cplx(e[1:])
+    return r

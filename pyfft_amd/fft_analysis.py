@@ -396,49 +396,29 @@ def fft_pwelch(tvec, sigx, sigy, tbounds=None, Navr=None, windowoverlap=None, wi
         info.phixy_seg = np.angle(info.Pxy_seg)
         info.varphi_seg = np.zeros_like(info.phixy_seg)
 
-    # ---- epilogue (fft_analysis.py:489-648); length-nfft inverse FFTs run on the GPU
-    Cxy, Cxy2 = Cxy_Cxy2(Pxx, Pyy, Pxy)
+    # ---- epilogue (fft_analysis.py:489-648) on the device (sp_csd_epilogue: coherence, phase, amplitude spectra, the
+    # correlations by length-nfft inverse FFTs); the variance formulas are O(nfft) host lines on its results
+    ep = _E.csd_epilogue(np.real(Pxx), np.ascontiguousarray(np.real(Pyy).T), np.ascontiguousarray(Pxy.T), nfft, onesided,
+                         info.ENBW)
+    Cxy = np.ascontiguousarray(ep["Cxy"].T)
+    Cxy2 = np.ascontiguousarray(ep["Cxy2"].T).astype(np.complex128)
     info.varCxy = ((1.0 - Cxy * np.conjugate(Cxy)) / np.sqrt(2 * Navr)) ** 2.0
     info.varCxy2 = 4.0 * Cxy2 * info.varCxy
     info.varPxx = (Pxx / np.sqrt(Navr)) ** 2.0
     info.varPyy = (Pyy / np.sqrt(Navr)) ** 2.0
     info.varPxy = (Pxy / np.sqrt(Navr)) ** 2.0
     info.varPhxy = (np.sqrt(1.0 - np.abs(Cxy2))) / np.sqrt(2 * Navr * np.sqrt(np.abs(Cxy2))) ** 2.0
-    phi_xy = np.arctan2(Pxy.imag, Pxy.real)
-    info.Lxx = np.sqrt(np.abs(info.ENBW * Pxx))
-    info.Lyy = np.sqrt(np.abs(info.ENBW * Pyy))
-    info.Lxy = np.sqrt(np.abs(info.ENBW * Pxy))
-    if onesided:
-        info.Lxx[1:-1] = np.sqrt(2) * info.Lxx[1:-1]
-        info.Lyy[1:-1, :] = np.sqrt(2) * info.Lyy[1:-1, :]
-        info.Lxy[1:-1, :] = np.sqrt(2) * info.Lxy[1:-1, :]
-        if nfft % 2:
-            info.Lxx[-1] = np.sqrt(2) * info.Lxx[-1]
-            info.Lyy[-1, :] = np.sqrt(2) * info.Lyy[-1, :]
-            info.Lxy[-1, :] = np.sqrt(2) * info.Lxy[-1, :]
-
-        def halve(P):
-            R = P.copy()
-            R[1:-1, ...] *= 0.5
-            if nfft % 2:
-                R[-1, ...] *= 0.5
-            return R
-        info.Rxx = _ifft_cols(halve(Pxx), nfft, True)
-        info.Ryy = _ifft_cols(halve(Pyy), nfft, True)
-        info.Rxy = _ifft_cols(halve(Pxy), nfft, True)
-        info.iCxy = _ifft_cols(Cxy.copy(), nfft, True)
-    else:
-        info.Rxx = _ifft_cols(np.fft.ifftshift(Pxx, axes=0), nfft, False)
-        info.Ryy = _ifft_cols(np.fft.ifftshift(Pyy, axes=0), nfft, False)
-        info.Rxy = _ifft_cols(np.fft.ifftshift(Pxy, axes=0), nfft, False)
-        info.iCxy = _ifft_cols(np.fft.ifftshift(Cxy, axes=0), nfft, False)
-    s = np.sqrt(nfft)
-    info.Rxx, info.Ryy, info.Rxy, info.iCxy = info.Rxx * s, info.Ryy * s, info.Rxy * s, info.iCxy * s
-    info.Ex = info.Rxx[0, ...].copy()
-    info.Ey = info.Ryy[0, ...].copy()
-    info.corrcoef = info.Rxy / np.sqrt(np.ones((nfft, 1), dtype=info.Rxy.dtype) * (info.Ex * info.Ey))
-    for k in ("Rxx", "Ryy", "Rxy", "iCxy", "corrcoef"):
-        setattr(info, k, np.fft.fftshift(getattr(info, k), axes=0))
+    phi_xy = np.ascontiguousarray(ep["phi"].T)
+    info.Lxx = ep["Lxx"].copy()
+    info.Lyy = np.ascontiguousarray(ep["Lyy"].T)
+    info.Lxy = np.ascontiguousarray(ep["Lxy"].T)
+    info.Rxx = ep["Rxx"].copy()
+    info.Ryy = np.ascontiguousarray(ep["Ryy"].T)
+    info.Rxy = np.ascontiguousarray(ep["Rxy"].T)
+    info.iCxy = np.ascontiguousarray(ep["iCxy"].T)
+    info.corrcoef = np.ascontiguousarray(ep["corrcoef"].T)
+    info.Ex = np.asarray(ep["Ex"]).copy()
+    info.Ey = np.asarray(ep["Ey"]).copy()
     info.lags = (np.asarray(range(1, nfft + 1), dtype=int) - Nnyquist) / Fs
     info.varLxx = (info.Lxx ** 2) * (info.varPxx / np.abs(Pxx) ** 2)
     info.varLyy = (info.Lyy ** 2) * (info.varPyy / np.abs(Pyy) ** 2)

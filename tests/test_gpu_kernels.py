@@ -619,3 +619,54 @@ def test_welch_csd_reference_once_path(E, nfft, hop, n, nch, detrend, monkeypatc
     for u, v, w in zip(a, b, c):
         assert np.max(np.abs(u - w)) <= 3e-5 * np.abs(w).max()
         assert np.max(np.abs(v - w)) <= 3e-5 * np.abs(w).max()
+
+
+# ---------------------------------------------------------------- A6 / N1 epilogue on device-resident spectra
+@pytest.mark.parametrize("nfft,onesided", [(1024, True), (1333, True), (512, False), (777, False)])
+def test_csd_epilogue_on_device(E, nfft, onesided):
+    """coherence / phase / amplitude spectra / correlations from averaged spectra that never leave the GPU
+    (fft_analysis.py:489-648), against the same algebra in numpy float64"""
+    import torch
+    rng = np.random.default_rng(nfft)
+    nch = 3
+    nb = ((nfft + 1) // 2 if nfft % 2 else nfft // 2) if onesided else nfft
+    pxx = 1.0 + rng.random(nb)
+    pyy = 0.5 + rng.random((nch, nb))
+    pxy = (rng.standard_normal((nch, nb)) + 1j * rng.standard_normal((nch, nb))) * 0.4
+    enbw = 3.7
+    r = E.csd_epilogue(torch.from_numpy(pxx).cuda(), torch.from_numpy(pyy).cuda(), torch.from_numpy(pxy).cuda(), nfft, onesided, enbw)
+    assert all(v.is_cuda for v in r.values())
+    g = {k: v.cpu().numpy() for k, v in r.items()}
+    h = E.csd_epilogue(pxx, pyy, pxy, nfft, onesided, enbw)              # host arrays through the same kernels
+    for k in g:
+        np.testing.assert_allclose(g[k], h[k], rtol=0, atol=0)
+    den = np.abs(pxx)[None, :] * np.abs(pyy)
+    np.testing.assert_allclose(g["Cxy"], pxy / np.sqrt(den), rtol=1e-12)
+    np.testing.assert_allclose(g["Cxy2"], np.abs(pxy) ** 2 / den, rtol=1e-12)
+    np.testing.assert_allclose(g["phi"], np.angle(pxy), rtol=1e-12)
+    amp = np.ones(nb)
+    if onesided:
+        amp[1:-1] = np.sqrt(2)
+        if nfft % 2:
+            amp[-1] = np.sqrt(2)
+    np.testing.assert_allclose(g["Lxx"], amp * np.sqrt(enbw * pxx), rtol=1e-12)
+    np.testing.assert_allclose(g["Lxy"], amp * np.sqrt(enbw * np.abs(pxy)), rtol=1e-12)
+
+    def back(P, halve=True):
+        P = np.array(P, dtype=np.complex128)
+        if onesided:
+            if halve:
+                P[..., 1:-1] *= 0.5
+                if nfft % 2:
+                    P[..., -1] *= 0.5
+            return np.sqrt(nfft) * np.fft.irfft(P, n=nfft, axis=-1)
+        return np.sqrt(nfft) * np.fft.ifft(np.fft.ifftshift(P, axes=-1), n=nfft, axis=-1)
+    Rxx, Ryy, Rxy = back(pxx), back(pyy), back(pxy)
+    sc = np.abs(Rxx).max()
+    for name, ref in (("Rxx", Rxx), ("Ryy", Ryy), ("Rxy", Rxy), ("iCxy", back(pxy / np.sqrt(den), halve=False))):
+        assert np.max(np.abs(g[name] - np.fft.fftshift(ref, axes=-1))) <= 2e-6 * max(sc, np.abs(ref).max()), name
+    Ex, Ey = Rxx[0], Ryy[:, 0]
+    np.testing.assert_allclose(g["Ex"], Ex, rtol=1e-5)
+    np.testing.assert_allclose(g["Ey"], Ey, rtol=1e-5)
+    cc = np.fft.fftshift(Rxy, axes=-1) / np.sqrt(Ex * Ey)[:, None]
+    assert np.max(np.abs(g["corrcoef"] - cc)) <= 1e-5 * np.abs(cc).max()
