@@ -562,7 +562,7 @@ def csd_epilogue(pxx, pyy, pxy, nfft, onesided, enbw):
         out = torch.empty(n_out, dtype=torch.float64, device=a.device)
         check(lib().sp_csd_epilogue(ptr(a.data_ptr()), ptr(b.data_ptr()), ptr(c.data_ptr()), nch, nb, nfft, 1 if onesided else 0,
                                     float(enbw), ptr(out.data_ptr()), 1))
-        cplx = torch.view_as_complex
+        cplx = lambda v: torch.complex(v[..., 0], v[..., 1])          # noqa: E731  (slices of `out` may start at odd offsets)
     else:
         a = np.ascontiguousarray(np.real(pxx), dtype=np.float64)
         b = np.ascontiguousarray(np.real(pyy), dtype=np.float64)
