@@ -894,10 +894,50 @@ class fftanal(Struct):
             self.freq = freq[:self.Nnyquist] if self.onesided else np.fft.fftshift(freq)
         self.averagewins()
 
+    def _scipy_stft(self, sig):
+        """scipy.signal.stft(sig, fs, window=self.win, nperseg=nwins, noverlap, nfft=nwins, detrend=self.detrend,
+        return_onesided, boundary='zeros', padded=True) as the reference calls it (fft_analysis.py:1814-1822), frames on
+        the GPU: zero extension by nperseg // 2 on both sides, zero padding to a whole number of hops, scaling
+        1 / sum(window), bins 0..nfft/2 (one-sided) or all bins in fftfreq order.  `self.detrend` is a callable whose
+        default axis is 0, so scipy removes the mean / line ACROSS segments at every sample position (reference quirk);
+        that is linear in the segments, hence applied to the spectra.  -> (freq, t, Zxx[nfreq, nseg])"""
+        nper, hop = self.nwins, self.nwins - self.noverlap
+        x = np.asarray(sig)
+        dt = np.complex128 if np.iscomplexobj(x) else np.float64
+        x = np.concatenate([np.zeros(nper // 2, dtype=dt), x, np.zeros(nper // 2, dtype=dt)])
+        nadd = (-(x.shape[-1] - nper) % hop) % nper
+        x = np.concatenate([x, np.zeros(nadd, dtype=dt)])
+        nseg = (x.shape[-1] - nper) // hop + 1
+        win = np.asarray(self.win, dtype=np.float64)
+        Z, _ = _E.stft_frames(x, win, hop, nseg, detrend=False, sided=_E.SIDED_HALF if self.onesided else _E.SIDED_RAW,
+                              amp_scale=1.0 / np.sum(win))
+        Z = np.asarray(Z).astype(np.complex128)
+        d = _check_detrend(self.detrendstyle)
+        if d == 1:
+            Z = Z - Z.mean(axis=0, keepdims=True)
+        elif d == 2 and nseg > 1:
+            g = np.arange(nseg, dtype=np.float64) - 0.5 * (nseg - 1)
+            slope = (g[:, None] * Z).sum(axis=0) / np.sum(g * g)
+            Z = Z - Z.mean(axis=0, keepdims=True) - g[:, None] * slope[None, :]
+        freq = np.fft.rfftfreq(nper, 1.0 / self.Fs) if self.onesided else np.fft.fftfreq(nper, 1.0 / self.Fs)
+        t = np.arange(nper / 2.0, x.shape[-1] - nper / 2.0 + 1, hop) / float(self.Fs) - (nper / 2.0) / self.Fs
+        return freq, t, np.ascontiguousarray(Z.T)
+
     def stft(self):
         if self.useMLAB:
-            # the reference switches to scipy.signal.stft here (:1806-1824: zero-padded boundaries, padded frames)
-            raise NotImplementedError("fftanal.stft with useMLAB=True (scipy.signal.stft branch); fftpwelch() supports useMLAB")
+            # the scipy.signal.stft branch (fft_analysis.py:1806-1824).  Its spectra are [frequency, segment]; the reference
+            # then runs Pstft() and averagewins() on that layout: the segment means are taken along axis 0 (= frequency)
+            # and Cxy_Cxy2 fails on the resulting 1-D arrays (IndexError at :1669) -- the same attributes are set in the
+            # same order and the same exception type is raised.
+            self.freq, self.tseg, self.Xseg = self._scipy_stft(self.sigx)
+            _, _, self.Yseg = self._scipy_stft(self.sigy)
+            self.Pstft()
+            for p in ("Pxx", "Pyy", "Pxy"):
+                setattr(self, p, np.mean(getattr(self, p + "_seg"), axis=0))
+                setattr(self, "var" + p, (getattr(self, p) / np.sqrt(self.Navr)) ** 2.0)
+            self.phi_xy = np.angle(self.Pxy)
+            raise IndexError("tuple index out of range (reference behaviour: Cxy_Cxy2 on the 1-D means of the "
+                             "[frequency, segment] spectra, fft_analysis.py:1669)")
         self.pwelch()
 
     def fftpwelch(self):

@@ -649,3 +649,32 @@ def test_doppler_cog_streaming_and_generic_paths_agree(P, monkeypatch):
                 _, ref = O.cog_frames(t, x - (x.mean() if kw.get("detrend") else 0), fs, win=win, ov=ov,
                                       **{k: v for k, v in kw.items() if k != "detrend"})
                 np.testing.assert_allclose(a, ref, rtol=0, atol=3e-6 * fs)
+
+
+@pytest.mark.parametrize("tag,kw", [("one_mean", dict(onesided=True, detrend=1)), ("two_none", dict(onesided=False, detrend=0)),
+                                    ("one_linear", dict(onesided=True, detrend=-1))])
+def test_fftanal_stft_usemlab_scipy_branch(P, tag, kw):
+    """fftanal.stft() with useMLAB=True = the scipy.signal.stft branch (fft_analysis.py:1805-1824): zero-extended
+    boundaries, padded frames, 1/sum(window) scaling, detrend across segments; fixture from the reference
+    (make_golden_stftmlab.py), including the IndexError its averagewins step ends in"""
+    g = load_golden("stft_usemlab")
+    rng = np.random.default_rng(int(g["seed"]))
+    n = int(g["n"])
+    t = np.arange(n) / 2.0e3
+    x = np.sin(2 * np.pi * 120.0 * t) + 0.2 * rng.standard_normal(n) + 0.7
+    y = np.cos(2 * np.pi * 120.0 * t + 0.4) + 0.2 * rng.standard_normal(n) - 0.3 + 0.1 * t
+    ft = P.fftanal(t, x, y, tbounds=[t[0], t[-1]], Navr=12, windowoverlap=0.5, windowfunction="hamming", useMLAB=True,
+                   plotit=False, verbose=False, **kw)
+    assert ft.nwins == int(g["nwins_" + tag]) and ft.noverlap == int(g["noverlap_" + tag])
+    with pytest.raises(IndexError):
+        ft.stft()
+    assert str(g["err_" + tag]) == "IndexError"
+    np.testing.assert_allclose(ft.freq, g["freq_" + tag], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(ft.tseg, g["tseg_" + tag], rtol=1e-12, atol=1e-12)
+    for k in ("Xseg", "Yseg"):
+        ref = g[k + "_" + tag]
+        assert getattr(ft, k).shape == ref.shape
+        assert np.max(np.abs(getattr(ft, k) - ref)) <= 1e-4 * np.abs(ref).max(), k
+    for k in ("Pxx", "Pxy", "varPxx"):
+        ref = g[k + "_" + tag]
+        np.testing.assert_allclose(getattr(ft, k), ref, rtol=3e-4, atol=1e-6 * np.abs(ref).max(), err_msg=k)
