@@ -177,7 +177,8 @@ int launch_csdm_mfma(LaunchCtx c, const cf *Xt, int nch, int nchp, int64_t mp, i
 
 // fused path (nch <= 64: one channel superblock): bins [0, 16*ngroups) straight from Xs; the remaining 1..16 bins
 // through a gathered copy + k_csdm_mfma
-int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G) {
+int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld) {
+    if (ld <= 0) ld = nb;                                  // row pitch of the spectra (>= nb)
     const int nchp = (nch + 63) / 64 * 64;
     const int ngroups = (nb - 1) / SP_CMF_BINS;
     if (ngroups > 0) {
@@ -196,13 +197,13 @@ int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m
             (void)hipFuncSetAttribute((const void *)k_csdm_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
-        hipLaunchKernelGGL(k_csdm_fused, dim3(ngroups * slices), dim3(1024), lds, c.stream, Xs, nch, m, nb, G, fs, slices,
+        hipLaunchKernelGGL(k_csdm_fused, dim3(ngroups * slices), dim3(1024), lds, c.stream, Xs, nch, m, ld, G, fs, slices,
                            slices > 1);
     }
     const int kfirst = SP_CMF_BINS * ngroups, ntail = nb - kfirst;
     if (ntail > 0) {
         const int64_t mp = (m + 31) / 32 * 32;
-        hipLaunchKernelGGL(k_csdm_gather_bins, dim3((unsigned)mp), dim3(256), 0, c.stream, Xs, Xt_tail, nch, nchp, m, mp, nb, kfirst,
+        hipLaunchKernelGGL(k_csdm_gather_bins, dim3((unsigned)mp), dim3(256), 0, c.stream, Xs, Xt_tail, nch, nchp, m, mp, ld, kfirst,
                            ntail);
         if (launch_csdm_mfma(c, Xt_tail, nch, nchp, mp, ntail, G + (int64_t)kfirst * nch * nch * 2)) return -1;
     }

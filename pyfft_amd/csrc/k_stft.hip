@@ -25,15 +25,15 @@ int launch_stft(LaunchCtx c, const void *x, bool cplx, const float *win, int hop
 // real input, power-of-two n >= 32: two frames per transform; rp partitions PAIRS of frames
 int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
                    const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg, int nchan,
-                   int64_t x_cs, int64_t out_cs) {
+                   int64_t x_cs, int64_t out_cs, int out_ld) {
 #define RP_(NN)                                                                                       \
     case NN:                                                                                          \
         if (lin) hipLaunchKernelGGL((k_stft_rp<NN, true>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG),          \
                                     WgCfg<NN>::lds_bytes(1), c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, sided, \
-                                    amp, out_power, out, pseg, x_cs, out_cs);                         \
+                                    amp, out_power, out, pseg, x_cs, out_cs, out_ld);                 \
         else hipLaunchKernelGGL((k_stft_rp<NN, false>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG),             \
                                 WgCfg<NN>::lds_bytes(1), c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, sided, amp, \
-                                out_power, out, pseg, x_cs, out_cs);                                  \
+                                out_power, out, pseg, x_cs, out_cs, out_ld);                          \
         break;
     switch (xf.L) {
         RP_(32) RP_(64) RP_(128) RP_(256) RP_(512) RP_(1024) RP_(2048) RP_(4096) RP_(8192)

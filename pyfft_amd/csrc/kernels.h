@@ -1564,7 +1564,8 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
                                                            int hop, int64_t nframes, int64_t ppg,
                                                            const float *__restrict__ trend, XfTables tb, int sided,
                                                            float amp, int out_power, void *__restrict__ out,
-                                                           double *__restrict__ pseg, int64_t x_cs, int64_t out_cs) {
+                                                           double *__restrict__ pseg, int64_t x_cs, int64_t out_cs,
+                                                           int out_ld /* row pitch of `out` in elements; 0: nbins */) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
     float w[C::R];
@@ -1574,7 +1575,7 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
     if (out_power) out = reinterpret_cast<float *>(out) + (int64_t)blockIdx.y * out_cs;
     else out = reinterpret_cast<cf *>(out) + (int64_t)blockIdx.y * out_cs;
     const Trend tr = load_trend(trend + 4 * blockIdx.y);
-    const int nb = nbins_of(n, sided);
+    const int nb = out_ld > 0 ? out_ld : nbins_of(n, sided);
     const int64_t npairs = (nframes + 1) / 2;
     const int64_t gid = (int64_t)blockIdx.x * C::FPW + grp;
     const int64_t p0 = gid * ppg;
@@ -2057,8 +2058,8 @@ static __global__ __launch_bounds__(256) void k_csdm_mfma(const cf *Xt, int nch,
 #define SP_CMF_F 4        // frames per tile
 #define SP_CMF_P 17       // LDS pitch (complex) of one (frame, channel) row
 #define SP_CMF_TILE (SP_CMF_F * 64 * SP_CMF_P)      // complex elements per buffer
-static __global__ __launch_bounds__(1024) void k_csdm_fused(const cf *Xs, int nch, int64_t m, int nb, double *__restrict__ G,
-                                                             int64_t fs, int slices, int atomic) {
+static __global__ __launch_bounds__(1024) void k_csdm_fused(const cf *Xs, int nch, int64_t m, int nb /* row pitch of Xs */,
+                                                             double *__restrict__ G, int64_t fs, int slices, int atomic) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *lds = reinterpret_cast<cf *>(smem_raw);
     constexpr int F = SP_CMF_F;
@@ -2166,7 +2167,7 @@ static __global__ __launch_bounds__(1024) void k_csdm_fused(const cf *Xs, int nc
 
 // tail bins for the fused path: Xt2[kk][g][c] = Xs[c][g][kfirst + kk], zero padded (kk < ntail <= 16)
 static __global__ void k_csdm_gather_bins(const cf *__restrict__ Xs, cf *__restrict__ Xt, int nch, int nchp, int64_t m, int64_t mp,
-                                          int nb, int kfirst, int ntail) {
+                                          int nb /* row pitch of Xs */, int kfirst, int ntail) {
     const int64_t g = blockIdx.x;
     for (int e = threadIdx.x; e < ntail * nchp; e += blockDim.x) {
         const int kk = e / nchp, c = e % nchp;

@@ -118,7 +118,7 @@ int launch_welch_rp(LaunchCtx c, const float *x, const float *win, int hop, int6
                     const Xf &xf, float *partial, const RunPart &rp);
 int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
                    const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg,
-                   int nchan = 1, int64_t x_cs = 0, int64_t out_cs = 0);
+                   int nchan = 1, int64_t x_cs = 0, int64_t out_cs = 0, int out_ld = 0);
 int launch_csd(LaunchCtx c, const void *x, const void *y, bool cplx, int nch, int64_t y_ld, const float *win, int hop,
                int64_t nframes, const float *trend_x, const float *trend_y, bool lin, const Xf &xf, float *partial,
                const RunPart &rp, int segmean = 0);
@@ -147,7 +147,7 @@ int launch_csdm_gemm(LaunchCtx c, const cf *Xt, int nch, int64_t mc, int nb, dou
 int launch_csdm_finish(LaunchCtx c, double *G, int nch, int nb, double scale, int blk);
 int launch_csdm_transpose_kgc(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int nchp, int64_t m, int64_t mp, int nb);
 int launch_csdm_mfma(LaunchCtx c, const cf *Xt, int nch, int nchp, int64_t mp, int nb, double *G);
-int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G);
+int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld = 0);
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out,
                    const cf *H = nullptr);
 int launch_spec_mul(LaunchCtx c, cf *X, const cf *H, int64_t n);

@@ -1233,7 +1233,12 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     const bool use_fused = use_mfma && nch <= 64 && !env_flag("SP_CSDM_TRANSPOSED");   // off-diagonal superblocks need 128 accumulators
     const int nchp = (nch + 63) / 64 * 64;                       // MFMA layout: channels padded to whole 64-superblocks,
     const int64_t mcp = (mc + 31) / 32 * 32;                     // frames to a multiple of 32 (zero filled)
-    const size_t sbytes = sizeof(cf) * (size_t)nch * (size_t)mc * (size_t)nb;
+    // fused path: every (channel, frame) row of the spectra starts on a 128-byte line (row pitch padded to a multiple of 16
+    // bins).  With the natural pitch nb = nfft/2 + 1 (odd) almost every 16-bin tile row straddled two lines and the
+    // contraction fetched 1.9x its algorithmic bytes (calibrated PMC: profiles/r02_fetch_size_calibration.txt)
+    const bool rp_stft = !xf.blue && xf.L >= 32 && nch <= 65535;
+    const int ld = (use_fused && rp_stft && !env_flag("SP_CSDM_NOPAD")) ? (nb + 15) / 16 * 16 : nb;
+    const size_t sbytes = sizeof(cf) * (size_t)nch * (size_t)mc * (size_t)ld;
     const size_t tbytes = use_fused ? sizeof(cf) * (size_t)nchp * (size_t)mcp * 16
                                     : (use_mfma ? sizeof(cf) * (size_t)nchp * (size_t)mcp * (size_t)nb : sbytes);
     if (g.cmS.ensure(sbytes) || g.cmT.ensure(tbytes)) return -1;
@@ -1242,12 +1247,12 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
         const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
         hipLaunchKernelGGL(k_trend_shift, dim3((nch + 63) / 64), dim3(64), 0, g.stream, tb.f, tb.f + 4 * nch, nch,
                            (double)f0 * (double)hop);
-        if (!xf.blue && xf.L >= 32 && m >= 2 && nch <= 65535) {
+        if (rp_stft && (m >= 2 || ld != nb)) {
             // all channels in one grid, two real frames per transform
             const RunPart rp = run_partition(xf.L, (m + 1) / 2, g.ncu, 1);
             LAUNCHCHK(launch_stft_rp(lc(), xd + (size_t)f0 * (size_t)hop, (const float *)win_d, hop, m, tb.f + 4 * nch,
                                      detrend == 2, xf, rp, SP_SIDED_HALF, 1.f, 0, Xs, nullptr, nch, x_ld,
-                                     (int64_t)m * nb));
+                                     (int64_t)m * ld, ld));
         } else {
             const RunPart rp = run_partition(xf.L, m, g.ncu, 2);
             for (int c = 0; c < nch; ++c)
@@ -1256,7 +1261,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                                       1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
         }
         if (use_fused) {
-            LAUNCHCHK(launch_csdm_fused(lc(), Xs, Xt, nch, m, nb, G));
+            LAUNCHCHK(launch_csdm_fused(lc(), Xs, Xt, nch, m, nb, G, ld));
         } else if (use_mfma) {
             const int64_t mp = (m + 31) / 32 * 32;
             LAUNCHCHK(launch_csdm_transpose_kgc(lc(), Xs, Xt, nch, nchp, m, mp, nb));
@@ -1313,7 +1318,7 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
             void *out, double *pseg_out, int mem) {
     if (ensure_init()) return -1;
     if (check_frames("sp_stft", nsig, nfft, hop, nframes)) return -1;
-    if (sided < 1 || sided > 3) return fail("sp_stft: bad sided");
+    if (sided < 1 || sided > 4) return fail("sp_stft: bad sided");
     if (detrend < 0 || detrend > 4) return fail("sp_stft: detrend must be 0..4");
     const int segmean = detrend == SP_DETREND_SEGMEAN ? 1 : (detrend == SP_DETREND_SEGLINEAR ? 2 : 0);   // per-window: generic kernel
     if (segmean) {

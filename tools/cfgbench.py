@@ -89,6 +89,14 @@ def main():
         report("cfg5 ref x 63 channels csd", ms, 4.0 * nch * n, nch * n, "samples")
         del x, G
 
+    if "biquad" in only:    # cfg4's "+ notch_filter": exact biquad over 2^28 float32
+        from pyfft_amd.notch_filter import iirnotch
+        n = 1 << 28
+        x = torch.randn(n, device=dev, dtype=torch.float32)
+        b, a_ = iirnotch(0.01, 30.0)
+        ms = timed(lambda: E.biquad_filter(b, a_, x), a.reps)
+        report("cfg4 notch (exact biquad) 2^28 f32", ms, 8.0 * n, n, "samples")
+        del x
     if "hilbert" in only:
         x = torch.randn((4096, 4096), generator=g, device=dev, dtype=torch.float32)
         ms, z = timed(lambda: E.hilbert_rows(x, 4096), a.reps)
