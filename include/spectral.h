@@ -42,6 +42,12 @@ extern "C" {
 int sp_init(int device_id);          /* select device, create context (idempotent)          */
 void sp_shutdown(void);              /* free plan cache + scratch                           */
 const char *sp_last_error(void);
+/* Concurrency contract: one global context under one lock -- calls from several threads serialise.  All launches go to
+ * ONE stream (the one set last); scratch buffers, the device-table cache and the pending state between sp_welch_accum and
+ * sp_welch_finish are shared by all calls.  sp_set_stream orders the new stream behind the work already queued on the
+ * old one (event), so consecutive calls from different streams are safe; truly concurrent use from two streams is not
+ * supported.  The table cache (windows, FFT(window), filter spectra; 64 entries, LRU) never evicts a table the current
+ * call obtained nor the tables a pending sp_welch_accum holds. */
 int sp_set_stream(void *hip_stream); /* hipStream_t for mem=1 calls (NULL = default stream) */
 int sp_synchronize(void);            /* wait for the library's stream                       */
 int sp_version(void);
@@ -65,7 +71,11 @@ int sp_fft_c2c(const void *in, void *out, int64_t n, int64_t batch, int directio
 /* ---- A3+A4: fftanal.fft_win -> Pstft -> averagewins (fft_analysis.py:2126-2203,
  *      :1944-1990), the fused Welch PSD: per frame g, X_g = FFT(win * (x[g*hop : g*hop+nfft] - trend));
  *      pxx[k] = scale/nframes * sum_g |X_g[k]|^2 with the sidedness permutation/doubling.
- *      nfft: any length >= 2 (non powers of two use the fused Bluestein path, up to sp_max_wg_fft()/2).
+ *      nfft: any length >= 2.  Powers of two up to sp_max_wg_fft() and other lengths up to half of it run in ONE fused
+ *      kernel (Bluestein inside the workgroup); longer segments -- the reference's default regime, Navr = 8 ->
+ *      nwins = floor(nsig / 4.5), fft_analysis.py:2412-2418 -- go through the multi-kernel long-segment path (pack ->
+ *      batched multi-pass FFT / chirp-z -> float64 accumulate; k_long.hip), up to a 2^26-point transform.  The same
+ *      holds for sp_welch_csd, sp_stft and sp_stft_cog.
  *      detrend (global detrend over x[0:nsig], fft_analysis.py:2148, :2539-2549):
  *        SP_DETREND_CONST  (0) subtract the given constant mean_re + i mean_im (0,0 = no detrend),
  *        SP_DETREND_MEAN   (1) the library computes and subtracts the mean (one extra pass over x),
