@@ -511,6 +511,10 @@ __global__ __launch_bounds__(X::C::WG) __attribute__((amdgpu_waves_per_eu(2, 2))
 #ifndef SP_CARRY_NBUF
 #define SP_CARRY_NBUF 1
 #endif
+// SP_NT_LOADS=1: the carry kernel's sample loads carry the non-temporal cache policy
+#ifndef SP_NT_LOADS
+#define SP_NT_LOADS 0
+#endif
 // (no min-waves hint: capping at 168 VGPRs makes hipcc spill the window registers and reload them inside the
 //  frame loop behind vmcnt(0) waits, which also drains the prefetch loads -- measured 2x slower)
 // COG: instead of accumulating |X|^2 over the frames, every frame's spectral moments sum ks|X|^2, sum |X|^2 (signed bin
@@ -568,8 +572,19 @@ __device__ __forceinline__ void welch_carry_body(
 #pragma unroll
             for (int s = 0; s < SHIFT; ++s) {
                 const unsigned off = (unsigned)(tid + C::T * s);
+#if SP_NT_LOADS
+                // the stream is read exactly once: non-temporal loads (nt) keep it from displacing the twiddle / window
+                // tables and the partial spectra in L2
+                if (CPLX) {
+                    const sp_f2v r = __builtin_nontemporal_load(reinterpret_cast<const sp_f2v *>(x) + ubase + off);
+                    dst[s] = mk(r.x, r.y);
+                } else {
+                    dst[s] = mk(__builtin_nontemporal_load(reinterpret_cast<const float *>(x) + ubase + off), 0.f);
+                }
+#else
                 if (CPLX) dst[s] = (reinterpret_cast<const cf *>(x) + ubase)[off];
                 else dst[s] = mk((reinterpret_cast<const float *>(x) + ubase)[off], 0.f);
+#endif
             }
         } else {
             const int64_t base = gn * hop + tid + (int64_t)C::T * KEEP;
