@@ -448,7 +448,11 @@ template <int N> struct FftPlan {
 
 // ---- the workgroup FFT ------------------------------------------------------------------
 // Forward transforms only (inverses are conj(fft(conj(.))) at the call sites).
-template <int N> struct WgFft {
+// TW1LDS: the constants of the FIRST twiddled radix-16 pass are not kept in registers but re-read every transform from a
+// 16-row table in LDS (`tw1`: row = tid % 16, SP_TW1_PITCH floats apart) -- only 16 distinct sets exist for that pass; frees
+// 40 VGPRs per thread (the occupancy experiment of the carry kernel, SP_CARRY_W3)
+#define SP_TW1_PITCH 44      /* 40 floats + 4: rows start 44 dwords apart -> the 16 rows of a b128 read hit 16 distinct bank quads */
+template <int N, bool TW1LDS = false> struct WgFft {
     using PL = FftPlan<N>;
     static constexpr int R = PL::R, T = PL::T, NP = PL::NP;
     static constexpr int N16 = PL::NP16 > 1 ? PL::NP16 - 1 : 0;          // twiddled radix-16 passes
@@ -460,6 +464,21 @@ template <int N> struct WgFft {
     Tw16 t16[N16 > 0 ? N16 : 1];
 #endif
     cf twr[NTR > 0 ? NTR : 1];
+    const float *tw1 = nullptr;
+
+    // TW1LDS: write this thread's pass-1 constants into row tid % 16 of the LDS table (threads 0..15 cover all rows); call
+    // after load_twiddles, followed by a barrier
+    __device__ __forceinline__ void publish_tw1(float *table, int tid) {
+#if !SP_PACKED
+        if constexpr (TW1LDS && N16 > 0) {
+            if (tid < 16) {
+#pragma unroll
+                for (int j = 0; j < 40; ++j) table[tid * SP_TW1_PITCH + j] = t16[0].f[j];
+            }
+            tw1 = table;
+        }
+#endif
+    }
 
     // table[m] = exp(-2 pi i m / N), m = 0..N-1
     __device__ __forceinline__ void load_twiddles(const cf *__restrict__ table, int tid) {
@@ -518,7 +537,19 @@ template <int N> struct WgFft {
                     if constexpr (P > 0 && !(SP_ABLATE & 4)) dft16p<true>(x, t16[SP_DIAG_SHARETW ? 0 : P - 1], k16);
                     else dft16p<false>(x, t16[0], k16);
 #else
-                    if constexpr (P > 0 && !(SP_ABLATE & 4)) {
+                    if constexpr (TW1LDS && P == 1 && !(SP_ABLATE & 4)) {
+                        Tw16 wl;
+                        const float4 *row = reinterpret_cast<const float4 *>(tw1 + (tid % 16) * SP_TW1_PITCH);
+#pragma unroll
+                        for (int j = 0; j < 10; ++j) {
+                            const float4 q = row[j];
+                            wl.f[4 * j] = q.x;
+                            wl.f[4 * j + 1] = q.y;
+                            wl.f[4 * j + 2] = q.z;
+                            wl.f[4 * j + 3] = q.w;
+                        }
+                        dft16s<true>(x, wl);
+                    } else if constexpr (P > 0 && !(SP_ABLATE & 4)) {
                         dft16s<true>(x, t16[SP_DIAG_SHARETW ? 0 : P - 1]);
                     } else {
                         dft16s<false>(x, t16[0]);

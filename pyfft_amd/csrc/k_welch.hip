@@ -26,7 +26,10 @@ static bool try_carry(LaunchCtx c, const void *x, const float *win, int hop, int
     using C = WgCfg<N>;
     const int shift = hop / C::T;
     constexpr bool HINT = N >= 512;       // see k_welch_carry / k_welch_carry_nh
-    const size_t lds = C::lds_bytes(SP_CARRY_NBUF) + carry_lds_pad();
+    size_t lds = C::lds_bytes(SP_CARRY_NBUF) + carry_lds_pad();
+#if SP_CARRY_W3
+    if (spartial && N == 4096 && C::FPW == 1) lds += sizeof(float) * (2 * (size_t)shift * C::T + 16 * SP_TW1_PITCH);
+#endif
 #define CARRY_(S)                                                                                     \
     case S:                                                                                           \
         if constexpr (HINT) {                                                                         \

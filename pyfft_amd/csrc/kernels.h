@@ -35,11 +35,11 @@ struct XfTables {
     int n;             // transform length
 };
 
-template <int N> struct XfPow2 {
+template <int N, bool TW1LDS = false> struct XfPow2 {
     static constexpr int L = N;
     static constexpr bool EXACT = true;      // n == L at compile time
     using C = WgCfg<N>;
-    WgFft<N> f;
+    WgFft<N, TW1LDS> f;
     __device__ __forceinline__ void init(const XfTables &tb, int tid) { f.load_twiddles(tb.tw, tid); }
     __device__ __forceinline__ void fwd(cf (&v)[C::R], cf *lds, int tid, int) const { f.template run<true>(v, lds, lds, tid); }
     // two exchange images (ping-pong): one barrier per exchange instead of two
@@ -511,6 +511,21 @@ __global__ __launch_bounds__(X::C::WG) __attribute__((amdgpu_waves_per_eu(2, 2))
 #ifndef SP_CARRY_NBUF
 #define SP_CARRY_NBUF 1
 #endif
+// SP_CARRY_W3=1 (experiment): the carry kernel at 3 waves per SIMD (<= 168 VGPRs): the pass-1 twiddle constants live in a
+// 2.8 KiB LDS table (40 floats re-read per thread and frame) and the one-pass block sums are accumulated by ds_add_f32 in
+// LDS (16 KiB per workgroup at hop 2048) instead of 16 VGPRs + 16 VALU adds
+#ifndef SP_CARRY_W3
+#define SP_CARRY_W3 0
+#endif
+#ifndef SP_W3_SUMS           /* 1: block sums by LDS atomics (with SP_CARRY_W3) */
+#define SP_W3_SUMS 1
+#endif
+#ifndef SP_W3_BOUND          /* waves per SIMD the W3 kernel is compiled for */
+#define SP_W3_BOUND 3
+#endif
+#ifndef SP_W3_TW             /* 1: pass-1 constants from the LDS table (with SP_CARRY_W3) */
+#define SP_W3_TW 1
+#endif
 // SP_NT_LOADS=1: the carry kernel's sample loads carry the non-temporal cache policy
 #ifndef SP_NT_LOADS
 #define SP_NT_LOADS 0
@@ -525,9 +540,20 @@ template <int N, bool CPLX, int SHIFT, bool ONEPASS, bool COG>
 __device__ __forceinline__ void welch_carry_body(
     const void *__restrict__ x, const float *__restrict__ win, int64_t nframes, int64_t fpg,
     const float *__restrict__ trend, XfTables tb, float *__restrict__ partial, cf *__restrict__ spartial) {
-    using X = XfPow2<N>;
+    constexpr bool W3 = SP_CARRY_W3 && ONEPASS && !COG && N == 4096 && WgCfg<N>::FPW == 1;
+    constexpr bool W3S = W3 && SP_W3_SUMS;
+    using X = XfPow2<N, W3 && SP_W3_TW>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
+    // W3: after the exchange image(s): block sums [SHIFT][2][T] floats, then the pass-1 constant table
+    float *lds_sums = reinterpret_cast<float *>(smem + C::FPW * C::LDS_PER * SP_CARRY_NBUF);
+    if constexpr (W3) {
+        float *tab = lds_sums + 2 * SHIFT * C::T;
+#pragma unroll
+        for (int s = 0; s < 2 * SHIFT; ++s) lds_sums[s * C::T + tid] = 0.f;
+        xf.f.publish_tw1(tab, tid);
+        __syncthreads();
+    }
     static_assert(!(COG && ONEPASS), "the moments mode has no one-pass detrend epilogue");
     static_assert(SHIFT >= 1 && SHIFT <= C::R, "hop must be 1..R register slots");
     constexpr int KEEP = C::R - SHIFT;
@@ -611,7 +637,15 @@ __device__ __forceinline__ void welch_carry_body(
     auto body = [&](int64_t i, cf (&fill)[SHIFT], int64_t fill_frame, cf (&take)[SHIFT]) __attribute__((always_inline)) {
         const int64_t g = g0 + i;
         const float keep = (UNI || g < nframes) ? 1.f : 0.f;
-        if (ONEPASS) {
+        if constexpr (W3S) {
+            // own slots, plain read-modify-write (ds_add_f32 measured ~300 cycles per wave-instruction: 3.1 ms kernel)
+            cf *ss = reinterpret_cast<cf *>(lds_sums);
+            cf cur[SHIFT];
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) cur[s] = ss[s * C::T + tid];
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) ss[s * C::T + tid] = cur[s] + raw[KEEP + s];
+        } else if (ONEPASS) {
 #pragma unroll
             for (int s = 0; s < SHIFT; ++s) sacc[s] = UNI ? sacc[s] + raw[KEEP + s] : sacc[s] + keep * raw[KEEP + s];
         }
@@ -675,7 +709,11 @@ __device__ __forceinline__ void welch_carry_body(
 #pragma unroll
         for (int t = 0; t < C::R; ++t) partial[gid * N + tid + C::T * t] = acc[t];
     }
-    if (ONEPASS) {
+    if constexpr (W3S) {
+#pragma unroll
+        for (int s = 0; s < SHIFT; ++s)
+            spartial[gid * hop + tid + C::T * s] = reinterpret_cast<cf *>(lds_sums)[s * C::T + tid];
+    } else if (ONEPASS) {
 #pragma unroll
         for (int s = 0; s < SHIFT; ++s) spartial[gid * hop + tid + C::T * s] = sacc[s];
     }
@@ -686,12 +724,21 @@ __device__ __forceinline__ void welch_carry_body(
 // still trades latency hiding for register pressure -- with it: 205 VGPRs and 3 % less time at the metric shape
 // (0.708 vs 0.731 ms on the same box, three interleaved rounds).  The moments kernel measured 2 % slower with the hint
 // and stays without.
+#if SP_CARRY_W3
+template <int N, bool CPLX, int SHIFT, bool ONEPASS>
+__global__ __launch_bounds__(WgCfg<N>::WG, (ONEPASS && N == 4096) ? SP_W3_BOUND : 2) void k_welch_carry(
+    const void *__restrict__ x, const float *__restrict__ win, int64_t nframes, int64_t fpg,
+    const float *__restrict__ trend, XfTables tb, float *__restrict__ partial, cf *__restrict__ spartial) {
+    welch_carry_body<N, CPLX, SHIFT, ONEPASS, false>(x, win, nframes, fpg, trend, tb, partial, spartial);
+}
+#else
 template <int N, bool CPLX, int SHIFT, bool ONEPASS>
 __global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_welch_carry(
     const void *__restrict__ x, const float *__restrict__ win, int64_t nframes, int64_t fpg,
     const float *__restrict__ trend, XfTables tb, float *__restrict__ partial, cf *__restrict__ spartial) {
     welch_carry_body<N, CPLX, SHIFT, ONEPASS, false>(x, win, nframes, fpg, trend, tb, partial, spartial);
 }
+#endif
 // (without the hint: the 256-point variants fit 3 waves per SIMD, 148-168 VGPRs, and must not be capped at 2)
 template <int N, bool CPLX, int SHIFT, bool ONEPASS>
 __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry_nh(
