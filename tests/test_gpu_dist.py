@@ -141,3 +141,70 @@ def test_two_ranks_one_gpu_sharded_cog_frames(tmp_path):
     for r in range(world):
         c = np.load(os.path.join(str(tmp_path), "c%d.npy" % r))
         np.testing.assert_allclose(c, ref, rtol=0, atol=3e-6 * 1.0e3)
+
+
+def _pipe_fir_worker(rank, world, port, total, nfft, hop, ntaps, out_dir):
+    import torch
+    import torch.distributed as dist
+    from pyfft_amd.dist import shard_plan, WelchPipeline, sample_shard_plan, fftfilt_sharded, stft_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    win = O.windows("Hanning", nwins=nfft)
+    plan = shard_plan(total, nfft, hop, world, rank)
+    pipe = WelchPipeline(win, plan, scale=1.0)
+    outs = []
+    for step in range(3):
+        rng = np.random.default_rng(900 + step)
+        stream = (rng.standard_normal(total) + 1j * rng.standard_normal(total) + (0.2 * step - 0.4j)).astype(np.complex64)
+        r = pipe.submit(torch.from_numpy(stream[plan.first_sample: plan.first_sample + plan.nsamples]).cuda())
+        if r is not None:
+            outs.append(r.cpu().numpy())
+    outs.append(pipe.flush().cpu().numpy())
+    # overlap-save FIR and STFT of one real stream dealt out to the ranks: no exchange on the data path
+    rng = np.random.default_rng(31)
+    xr = rng.standard_normal(total).astype(np.float32)
+    h = (rng.standard_normal(ntaps) / ntaps).astype(np.float32)
+    sp = sample_shard_plan(total, ntaps, world, rank)
+    y = fftfilt_sharded(h, torch.from_numpy(xr[sp.read_first: sp.read_first + sp.nread]).cuda(), sp)
+    S = stft_sharded(torch.from_numpy(xr[plan.first_sample: plan.first_sample + plan.nsamples]).cuda(), win, plan,
+                     mean_value=float(xr.astype(np.float64).mean()))
+    assert y.is_cuda and S.is_cuda
+    np.savez(os.path.join(out_dir, "q%d.npz" % rank), psd=np.stack(outs), y=y.cpu().numpy(), first=sp.first, last=sp.last,
+             S=S.cpu().numpy(), f0=plan.first_frame)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_one_gpu_pipeline_fir_stft(tmp_path):
+    """WelchPipeline (async all-reduce consumed one submit later), fftfilt_sharded (halo = ntaps - 1) and stft_sharded with
+    the HIP kernels on device tensors; results against the single-process oracle"""
+    import torch.multiprocessing as mp
+    world, total, nfft, hop, ntaps = 2, 4096 + 2048 * 150, 4096, 2048, 129
+    port = 30700 + os.getpid() % 300
+    mp.spawn(_pipe_fir_worker, args=(world, port, total, nfft, hop, ntaps, str(tmp_path)), nprocs=world, join=True)
+    win = O.windows("Hanning", nwins=nfft)
+    M = (total - nfft) // hop + 1
+    rng = np.random.default_rng(31)
+    xr = rng.standard_normal(total).astype(np.float32)
+    h = (rng.standard_normal(ntaps) / ntaps).astype(np.float32)
+    yref = O.fftfilt(h.astype(np.float64), xr.astype(np.float64))
+    xd = xr.astype(np.float64) - xr.astype(np.float64).mean()
+    covered = 0
+    for r in range(world):
+        d = np.load(os.path.join(str(tmp_path), "q%d.npz" % r))
+        for step in range(3):
+            g = np.random.default_rng(900 + step)
+            stream = (g.standard_normal(total) + 1j * g.standard_normal(total) + (0.2 * step - 0.4j)).astype(np.complex64)
+            ref = O.welch_psd_stream(stream, win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+            np.testing.assert_allclose(d["psd"][step], ref, rtol=2e-4, atol=1e-6 * ref.max())
+        a, b = int(d["first"]), int(d["last"])
+        assert np.max(np.abs(d["y"] - yref[a:b])) <= 1e-4 * np.abs(yref).max()
+        covered += b - a
+        f0 = int(d["f0"])
+        nf = d["S"].shape[0]
+        idx = (np.arange(f0, f0 + nf) * hop)[:, None] + np.arange(nfft)[None, :]
+        Sref = np.fft.fft(win[None, :] * xd[idx], axis=-1)[:, :nfft // 2]
+        Sref[:, 1:-1] *= np.sqrt(2.0)
+        assert np.max(np.abs(d["S"] - Sref)) <= 1e-4 * np.abs(Sref).max()
+    assert covered == total
