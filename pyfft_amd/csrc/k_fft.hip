@@ -182,17 +182,26 @@ int launch_hilbert_mask(LaunchCtx c, cf *X, int64_t n) {
     hipLaunchKernelGGL(k_hilbert_mask, dim3(ew_blocks(n, c.ncu)), dim3(256), 0, c.stream, X, n);
     return 0;
 }
-int launch_frame_sum(LaunchCtx c, const void *x, bool cplx, int64_t x_ld, int nch, int nfft, int hop, int64_t nframes,
-                     const float *trend, bool lin, double *out) {
-    // enough frame slices to fill the chip, each at least 8 frames long
+int frame_sum_slices(int ncu, int nch, int nfft, int64_t nframes) {
     const int nb = (nfft + 255) / 256;
-    int64_t slices = (8 * (int64_t)c.ncu + (int64_t)nb * nch - 1) / ((int64_t)nb * nch);
+    int64_t slices = (8 * (int64_t)ncu + (int64_t)nb * nch - 1) / ((int64_t)nb * nch);
     if (slices > (nframes + 7) / 8) slices = (nframes + 7) / 8;
     if (slices < 1) slices = 1;
     if (slices > 65535) slices = 65535;
+    return (int)slices;
+}
+// part: scratch of frame_sum_slices(...) * nch * nfft * 2 doubles
+int launch_frame_sum(LaunchCtx c, const void *x, bool cplx, int64_t x_ld, int nch, int nfft, int hop, int64_t nframes,
+                     const float *trend, bool lin, double *out, double *part) {
+    // enough frame slices to fill the chip, each at least 8 frames long
+    const int nb = (nfft + 255) / 256;
+    const int slices = frame_sum_slices(c.ncu, nch, nfft, nframes);
     const dim3 grid(nb, (unsigned)slices, nch);
-    if (lin) hipLaunchKernelGGL((k_frame_sum<true>), grid, dim3(256), 0, c.stream, x, cplx ? 1 : 0, x_ld, nfft, hop, nframes, trend, out);
-    else hipLaunchKernelGGL((k_frame_sum<false>), grid, dim3(256), 0, c.stream, x, cplx ? 1 : 0, x_ld, nfft, hop, nframes, trend, out);
+    if (lin) hipLaunchKernelGGL((k_frame_sum<true>), grid, dim3(256), 0, c.stream, x, cplx ? 1 : 0, x_ld, nfft, hop, nframes, trend, part);
+    else hipLaunchKernelGGL((k_frame_sum<false>), grid, dim3(256), 0, c.stream, x, cplx ? 1 : 0, x_ld, nfft, hop, nframes, trend, part);
+    const int64_t count = (int64_t)nch * nfft * 2;
+    hipLaunchKernelGGL(k_frame_sum_reduce, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c.stream, (const double *)part, slices,
+                       count, out);
     return 0;
 }
 int launch_spec_mul(LaunchCtx c, cf *X, const cf *H, int64_t n) {

@@ -1803,15 +1803,17 @@ static __global__ void k_hilbert_mask(cf *__restrict__ X, int64_t n) {
 }
 // c[ch][n] = sum_g detrended(x[ch][g*hop + n]), n < nfft: the time-domain sum of all frames of each channel.  By linearity
 // sum_g FFT(win * frame_g) = FFT(win * c): the mean spectrum of the nT-model branch of fft_pwelch (fft_analysis.py:346-393)
-// without writing one spectrum.  grid (ceil(nfft/256), frame slices, channels); float64 atomics into a zeroed out[ch][n][2].
+// without writing one spectrum.  grid (ceil(nfft/256), frame slices, channels); every slice writes its own partial
+// part[slice][ch][n][2] (float64), k_frame_sum_reduce adds the slices in a fixed order: deterministic (round 1 used
+// float64 atomics).
 template <bool LIN>
 static __global__ void k_frame_sum(const void *__restrict__ x, int cplx, int64_t x_ld, int nfft, int hop, int64_t nframes,
-                                   const float *__restrict__ trend, double *__restrict__ out) {
+                                   const float *__restrict__ trend, double *__restrict__ part) {
     const int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     const int ch = blockIdx.z;
     const int64_t per = (nframes + gridDim.y - 1) / gridDim.y;
     const int64_t g0 = (int64_t)blockIdx.y * per, g1 = g0 + per < nframes ? g0 + per : nframes;
-    if (n >= nfft || g0 >= g1) return;
+    if (n >= nfft) return;
     const Trend tr = load_trend(trend + 4 * ch);
     const int64_t off = (int64_t)ch * x_ld;
     double sr = 0.0, si = 0.0;
@@ -1821,8 +1823,17 @@ static __global__ void k_frame_sum(const void *__restrict__ x, int cplx, int64_t
         sr += (double)v.x;
         si += (double)v.y;
     }
-    atomicAdd(&out[2 * ((int64_t)ch * nfft + n)], sr);
-    atomicAdd(&out[2 * ((int64_t)ch * nfft + n) + 1], si);
+    double *p = part + 2 * (((int64_t)blockIdx.y * gridDim.z + ch) * nfft + n);
+    p[0] = sr;
+    p[1] = si;
+}
+static __global__ void k_frame_sum_reduce(const double *__restrict__ part, int slices, int64_t count /* nch*nfft*2 */,
+                                          double *__restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    double s = 0.0;
+    for (int q = 0; q < slices; ++q) s += part[(int64_t)q * count + e];
+    out[e] = s;
 }
 // X[k] *= H[k] in place (long-row form of sp_spectral_filter)
 static __global__ void k_spec_mul(cf *__restrict__ X, const cf *__restrict__ H, int64_t n) {

@@ -151,8 +151,9 @@ int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out,
                    const cf *H = nullptr);
 int launch_spec_mul(LaunchCtx c, cf *X, const cf *H, int64_t n);
+int frame_sum_slices(int ncu, int nch, int nfft, int64_t nframes);
 int launch_frame_sum(LaunchCtx c, const void *x, bool cplx, int64_t x_ld, int nch, int nfft, int hop, int64_t nframes,
-                     const float *trend, bool lin, double *out);
+                     const float *trend, bool lin, double *out, double *part);
 int launch_fftfilt(LaunchCtx c, const float *x, int64_t n, int ntaps, const cf *Hs, const Xf &xf, float *y);
 int launch_xcorr(LaunchCtx c, const float *x1, const float *x2, int64_t n, const double *mom, const Xf &xf, float *co);
 int launch_moments(LaunchCtx c, const void *x, bool cplx, int64_t n, int mode, double *partial_scratch, double *out_d,

@@ -1534,8 +1534,9 @@ int sp_frame_sum(const void *x, int x_dtype, int64_t nsig, int nch, int64_t x_ld
         if (g.out0.ensure(obytes)) return -1;
         od = (double *)g.out0.p;
     }
-    HIPCHK(hipMemsetAsync(od, 0, obytes, g.stream));
-    LAUNCHCHK(launch_frame_sum(lc(), xd, cplx, x_ld, nch, nfft, hop, nframes, tb.f + 4, detrend == 2, od));
+    const size_t pbytes = obytes * (size_t)frame_sum_slices(g.ncu, nch, nfft, nframes);
+    if (g.work.ensure(pbytes)) return -1;
+    LAUNCHCHK(launch_frame_sum(lc(), xd, cplx, x_ld, nch, nfft, hop, nframes, tb.f + 4, detrend == 2, od, (double *)g.work.p));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(out, od, obytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
