@@ -419,7 +419,14 @@ int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 
         // (each pass already fills the chip at these lengths)
         if (g.bigT.ensure(sizeof(cf) * (size_t)N)) return -1;
         cf *tmp = (cf *)g.bigT.p;
-        const int la_ = (lg + 2) / 3, lb_ = (lg - la_ + 1) / 2, lc_ = lg - la_ - lb_;
+        // the two COLUMN passes want short transforms: a workgroup then owns many adjacent columns and every access is a
+        // whole 128-byte line or more (256 points: 16 columns; 512 points would be 8 columns = 64-byte segments, measured
+        // 1.4 TB/s for that pass at 2^25 points) -- A, B <= 256, the rest goes to the contiguous row pass
+        int la_ = (lg + 2) / 3;
+        if (la_ > 8) la_ = 8;
+        int lb_ = (lg - la_ + 1) / 2;
+        if (lb_ > 8) lb_ = 8;
+        const int lc_ = lg - la_ - lb_;
         const int64_t A = (int64_t)1 << la_, B = (int64_t)1 << lb_, C = (int64_t)1 << lc_;
         Xf xa, xb, xc;
         if (get_xf(A, &xa) || get_xf(B, &xb) || get_xf(C, &xc)) return -1;
