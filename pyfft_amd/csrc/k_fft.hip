@@ -30,7 +30,7 @@ int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_
 
 // three-pass long transform pieces (power-of-two lengths; ncols is a multiple of the columns per workgroup)
 int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
-                    int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n) {
+                    int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n, ColsIn ci) {
     if (xf.blue) return -1;
     const int fpw = fpw_of(xf.L);
     if (ncols % fpw || nouter < 1) return -1;
@@ -39,13 +39,14 @@ int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t n
     const unsigned grid = (unsigned)(total < cap ? total : cap);
 #define M_(XT)                                                                                        \
     hipLaunchKernelGGL((k_fft_cols<XT::L>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, ncb, nouter, es, \
-                       os, twmul, conj_in, xf.tb, bt, hmask_n);
+                       os, twmul, conj_in, xf.tb, bt, hmask_n, ci);
     SP_DISPATCH_P(xf, M_)
 #undef M_
     return 0;
 }
 
-int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B, int conj_out, float scale, const Xf &xf) {
+int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B, int conj_out, float scale, const Xf &xf,
+                        RowsOut ro) {
     if (xf.blue) return -1;
     const int fpw = fpw_of(xf.L);
     if (A % fpw) return -1;
@@ -53,7 +54,7 @@ int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B
     const unsigned grid = (unsigned)(total < cap ? total : cap);
 #define M_(XT)                                                                                        \
     hipLaunchKernelGGL((k_fft_rows_rev<XT::L>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
-                       conj_out, scale, xf.tb);
+                       conj_out, scale, xf.tb, ro);
     SP_DISPATCH_P(xf, M_)
 #undef M_
     return 0;

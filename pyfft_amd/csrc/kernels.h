@@ -309,10 +309,23 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restri
 // k_fft_cols: a workgroup owns FPW ADJACENT columns and its lanes run over the columns (group = thread % FPW, the
 // flipped mapping), so that element i of the FPW columns is one contiguous segment (128 B at L = 256).
 // ------------------------------------------------------------------------------------------
+// Fused input forms of the FIRST pass (the element index base + i*es is then the sample / bin index of the whole
+// transform), so that the elementwise kernels in front of a long transform and their round trips through HBM disappear:
+//   kind 1: real samples, zero-padded: (r1[i] - m1, r2 ? r2[i] - m2 : 0) for i < nreal, else 0  (Hilbert's real -> complex
+//           pack; ccf's z = (x1 - m1) + i (x2 - m2): mom[0], mom[1] are the means; the zero half is not even loaded)
+//   kind 2: ccf's middle step on the fly from Z = FFT(z): R[k] = conj(A conj(B)) (see k_xc_mid), needs Z[k] and Z[L-k]
+struct ColsIn {
+    int kind;
+    const float *r1, *r2;
+    const double *mom;
+    int64_t nreal;
+    const cf *Z;
+    int64_t L;
+};
 template <int L>
 __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
                                                             int64_t nouter, int64_t es, int64_t os, int64_t twmul, int conj_in,
-                                                            XfTables tb, BigTw bt, int64_t hmask_n) {
+                                                            XfTables tb, BigTw bt, int64_t hmask_n, ColsIn ci) {
     using X = XfPow2<L>;
     using C = typename X::C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -330,8 +343,28 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_cols(const cf *__restrict_
         const int64_t col = (idx % ncolblocks) * C::FPW + grp;
         const int64_t base = (idx / ncolblocks) * os + col;
         cf v[C::R];
+        if (ci.kind == 1) {
+            const float m1 = ci.mom ? (float)ci.mom[0] : 0.f, m2 = ci.mom ? (float)ci.mom[1] : 0.f;
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t i = base + (int64_t)(tid + C::T * t) * es;
+                const bool ok = i < ci.nreal;
+                const int64_t ic = ok ? i : 0;
+                const float a = ci.r1[ic], b = ci.r2 ? ci.r2[ic] : m2;
+                v[t] = ok ? mk(a - m1, b - m2) : mk(0.f, 0.f);
+            }
+        } else if (ci.kind == 2) {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t k = base + (int64_t)(tid + C::T * t) * es;
+                const cf z = ci.Z[k], zm = ci.Z[(ci.L - k) & (ci.L - 1)];
+                const cf zz = cmul(z, zm);
+                v[t] = mk(0.5f * zz.y, -0.25f * (cnorm(z) - cnorm(zm)));
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
+        }
         if (hmask_n > 0) {
             // analytic-signal mask (hilbert.py:63-64) applied while loading the spectrum for the inverse transform
             // (pass 1 only: base + i*es is the bin index): k = 0 and k = nyq x1, 1..nyq-1 x2, above x0
@@ -359,9 +392,16 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_cols(const cf *__restrict_
 
 // pass 3: rows (ka, kb) of T[ka][kb][c]; the FPW rows of a workgroup are adjacent ka of one kb, so that for one kc the
 // workgroup's outputs X[ka + A kb + A B kc] are contiguous
+// RowsOut (ccf): instead of the complex spectrum, write co[lag + n - 1] = mom[2] / Ltot * Re X[j] for the lags |lag| < n
+// (lag = j for j < n, j - Ltot for j > Ltot - n; see k_xc_out) -- the last elementwise kernel of the long ccf, fused
+struct RowsOut {
+    float *co;
+    int64_t n, Ltot;
+    const double *mom;
+};
 template <int L>
 __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restrict__ in, cf *__restrict__ out, int64_t A, int64_t B,
-                                                                int conj_out, float scale, XfTables tb) {
+                                                                int conj_out, float scale, XfTables tb, RowsOut ro) {
     using X = XfPow2<L>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
@@ -376,8 +416,18 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restr
         for (int t = 0; t < C::R; ++t) v[t] = row[tid + C::T * t];
         xf.fwd(v, lds, tid, L);
         const int64_t off = kb * A + ka;
+        if (ro.co != nullptr) {
+            const float nrm = (float)(ro.mom[2] / (double)ro.Ltot);
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) out[(int64_t)(tid + C::T * t) * AB + off] = mk(scale * v[t].x, so * scale * v[t].y);
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t j = (int64_t)(tid + C::T * t) * AB + off;
+                if (j < ro.n) ro.co[j + ro.n - 1] = nrm * v[t].x;
+                else if (j > ro.Ltot - ro.n) ro.co[j - ro.Ltot + ro.n - 1] = nrm * v[t].x;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) out[(int64_t)(tid + C::T * t) * AB + off] = mk(scale * v[t].x, so * scale * v[t].y);
+        }
     }
 }
 

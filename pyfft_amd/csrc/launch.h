@@ -88,8 +88,10 @@ int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int invers
 int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_t in_rs, int64_t in_es, int64_t out_rs,
                        int64_t out_es, int conj_in, int conj_out, float scale, const Xf &xf, BigTw bt);
 int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
-                    int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n = 0);
-int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B, int conj_out, float scale, const Xf &xf);
+                    int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n = 0,
+                    ColsIn ci = ColsIn{0, nullptr, nullptr, nullptr, 0, nullptr, 0});
+int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B, int conj_out, float scale, const Xf &xf,
+                        RowsOut ro = RowsOut{nullptr, 0, 0, nullptr});
 // elementwise / transpose pieces of the long paths (k_fft.hip)
 int launch_transpose_c(LaunchCtx c, const cf *in, cf *out, int64_t rows, int64_t cols, int conj, float scale, int64_t batch = 1);
 int launch_pack_real(LaunchCtx c, const float *x, int64_t n_in, const double *mean, int64_t L, cf *out);

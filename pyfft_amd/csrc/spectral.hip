@@ -402,7 +402,12 @@ bool big_three_pass(int64_t N) {
     return is_pow2(N) && N >= ((int64_t)1 << 20) && !env_flag("SP_BIGFFT_5PASS") && !env_flag("SP_BIGFFT_2PASS");
 }
 
-int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 0, int64_t batch = 1) {
+// fused first-pass input / last-pass output of ONE three-pass transform (see ColsIn / RowsOut in kernels.h)
+struct BigFuse {
+    ColsIn ci = ColsIn{0, nullptr, nullptr, nullptr, 0, nullptr, 0};
+    RowsOut ro = RowsOut{nullptr, 0, 0, nullptr};
+};
+int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 0, int64_t batch = 1, const BigFuse *fz = nullptr) {
     int lg = 0;
     while (((int64_t)1 << lg) < N) ++lg;
     if (((int64_t)1 << lg) != N || lg > SP_MAX_BIG_LOG2) return fail("internal: dev_fft_big_pow2(%lld)", (long long)N);
@@ -413,7 +418,8 @@ int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 
     BigTw bt;
     if (get_bigtw(N, &bt)) return -1;
     const float sc = inverse ? (float)(1.0 / (double)N) : 1.f;
-    if (hmask && !big_three_pass(N)) return fail("internal: fused Hilbert mask needs the three-pass transform");
+    if ((hmask || fz) && !big_three_pass(N)) return fail("internal: fused Hilbert mask / pack need the three-pass transform");
+    if (fz && batch != 1) return fail("internal: fused long transform is a single transform");
     if (big_three_pass(N)) {
         // three passes over whole lines, N = A B C (kernels.h: k_fft_cols / k_fft_rows_rev); a batch runs row by row
         // (each pass already fills the chip at these lengths)
@@ -431,6 +437,12 @@ int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 
         Xf xa, xb, xc;
         if (get_xf(A, &xa) || get_xf(B, &xb) || get_xf(C, &xc)) return -1;
         for (int64_t b = 0; b < batch; ++b) {
+            if (fz) {
+                LAUNCHCHK(launch_fft_cols(lc(), in, tmp, B * C, 1, B * C, 0, 1, inverse, xa, bt, hmask ? N : 0, fz->ci));
+                LAUNCHCHK(launch_fft_cols(lc(), tmp, tmp, C, A, C, B * C, A, 0, xb, bt));
+                LAUNCHCHK(launch_fft_rows_rev(lc(), tmp, out, A, B, inverse, sc, xc, fz->ro));
+                continue;
+            }
             LAUNCHCHK(launch_fft_cols(lc(), in + b * N, tmp, B * C, 1, B * C, 0, 1, inverse, xa, bt, hmask ? N : 0));
             LAUNCHCHK(launch_fft_cols(lc(), tmp, tmp, C, A, C, B * C, A, 0, xb, bt));
             LAUNCHCHK(launch_fft_rows_rev(lc(), tmp, out + b * N, A, B, inverse, sc, xc));
@@ -1491,6 +1503,15 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
         if (g.bigA.ensure(sizeof(cf) * (size_t)nfft)) return -1;
         cf *A = (cf *)g.bigA.p;
         for (int64_t b = 0; b < batch; ++b) {
+            if (big_three_pass(nfft) && !env_flag("SP_LONG_NOFUSE")) {
+                // real -> complex pack fused into the first pass of the forward transform (the zero padding is not loaded),
+                // the analytic-signal mask into the first pass of the inverse one
+                BigFuse fz;
+                fz.ci = ColsIn{1, xd + b * x_ld, nullptr, nullptr, nuse, nullptr, 0};
+                if (dev_fft_big_pow2(A, A, nfft, 0, 0, 1, &fz)) return -1;
+                if (dev_fft_big_pow2(A, od + b * nfft, nfft, 1, 1)) return -1;
+                continue;
+            }
             LAUNCHCHK(launch_pack_real(lc(), xd + b * x_ld, nuse, nullptr, nfft, A));
             if (dev_fft_any(A, A, nfft, 1, 0)) return -1;
             if (big_three_pass(nfft)) {
@@ -1625,11 +1646,22 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
     } else {
         if (g.bigA.ensure(sizeof(cf) * (size_t)L) || g.bigB.ensure(sizeof(cf) * (size_t)L)) return -1;
         cf *A = (cf *)g.bigA.p, *B = (cf *)g.bigB.p;
-        LAUNCHCHK(launch_xc_pack(lc(), a, b, n, L, tb.d + 16, A));
-        if (dev_fft_big_pow2(A, B, L, 0)) return -1;
-        LAUNCHCHK(launch_xc_mid(lc(), B, L, A));                             // conj(A conj(B)) spectrum
-        if (dev_fft_big_pow2(A, B, L, 0)) return -1;                         // forward of the conjugate = L * real inverse
-        LAUNCHCHK(launch_xc_out(lc(), B, n, L, tb.d + 16, od));
+        if (big_three_pass(L) && !env_flag("SP_LONG_NOFUSE")) {
+            // the three elementwise kernels ride on the transforms: pack in the first pass of the first transform, the
+            // middle step in the first pass of the second, lag re-ordering + real part in its last pass
+            BigFuse f1, f2;
+            f1.ci = ColsIn{1, a, b, tb.d + 16, n, nullptr, 0};
+            if (dev_fft_big_pow2(A, B, L, 0, 0, 1, &f1)) return -1;          // B = FFT(z)
+            f2.ci = ColsIn{2, nullptr, nullptr, nullptr, 0, B, L};
+            f2.ro = RowsOut{od, n, L, tb.d + 16};
+            if (dev_fft_big_pow2(B, A, L, 0, 0, 1, &f2)) return -1;          // reads Z = B on the fly, writes co
+        } else {
+            LAUNCHCHK(launch_xc_pack(lc(), a, b, n, L, tb.d + 16, A));
+            if (dev_fft_big_pow2(A, B, L, 0)) return -1;
+            LAUNCHCHK(launch_xc_mid(lc(), B, L, A));                         // conj(A conj(B)) spectrum
+            if (dev_fft_big_pow2(A, B, L, 0)) return -1;                     // forward of the conjugate = L * real inverse
+            LAUNCHCHK(launch_xc_out(lc(), B, n, L, tb.d + 16, od));
+        }
     }
     if (!mem) {
         HIPCHK(hipMemcpyAsync(co_out, od, obytes, hipMemcpyDeviceToHost, g.stream));
