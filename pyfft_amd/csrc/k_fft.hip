@@ -38,8 +38,10 @@ int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t n
     const int64_t cap = (int64_t)c.ncu * 4;                    // several blocks per workgroup amortise its twiddle set-up
     const unsigned grid = (unsigned)(total < cap ? total : cap);
 #define M_(XT)                                                                                        \
-    hipLaunchKernelGGL((k_fft_cols<XT::L>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, ncb, nouter, es, \
-                       os, twmul, conj_in, xf.tb, bt, hmask_n, ci);
+    if (ci.kind == 1) hipLaunchKernelGGL((k_fft_cols<XT::L, 1>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, \
+                                         ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);                 \
+    else hipLaunchKernelGGL((k_fft_cols<XT::L, 0>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, ncb, nouter, \
+                            es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);
     SP_DISPATCH_P(xf, M_)
 #undef M_
     return 0;
@@ -53,8 +55,10 @@ int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B
     const int64_t total = A * B / fpw, cap = (int64_t)c.ncu * 4;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
 #define M_(XT)                                                                                        \
-    hipLaunchKernelGGL((k_fft_rows_rev<XT::L>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
-                       conj_out, scale, xf.tb, ro);
+    if (ro.co != nullptr) hipLaunchKernelGGL((k_fft_rows_rev<XT::L, true>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, \
+                                             in, out, A, B, conj_out, scale, xf.tb, ro);                               \
+    else hipLaunchKernelGGL((k_fft_rows_rev<XT::L, false>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
+                            conj_out, scale, xf.tb, ro);
     SP_DISPATCH_P(xf, M_)
 #undef M_
     return 0;

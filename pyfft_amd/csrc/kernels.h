@@ -313,17 +313,16 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restri
 // transform), so that the elementwise kernels in front of a long transform and their round trips through HBM disappear:
 //   kind 1: real samples, zero-padded: (r1[i] - m1, r2 ? r2[i] - m2 : 0) for i < nreal, else 0  (Hilbert's real -> complex
 //           pack; ccf's z = (x1 - m1) + i (x2 - m2): mom[0], mom[1] are the means; the zero half is not even loaded)
-//   kind 2: ccf's middle step on the fly from Z = FFT(z): R[k] = conj(A conj(B)) (see k_xc_mid), needs Z[k] and Z[L-k]
+// (ccf's middle step, R[k] from Z[k] and Z[L-k], was tried as a third form: 388 VGPRs, 132 spilled at the 2-wave cap --
+//  it stays its own kernel, k_xc_mid)
 struct ColsIn {
     int kind;
     const float *r1, *r2;
     const double *mom;
     int64_t nreal;
-    const cf *Z;
-    int64_t L;
 };
-template <int L>
-__global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
+template <int L, int KIND>   // KIND = ci.kind as a template parameter: as a run-time branch the load forms cost 306 VGPRs
+__global__ __launch_bounds__(WgCfg<L>::WG, 2) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
                                                             int64_t nouter, int64_t es, int64_t os, int64_t twmul, int conj_in,
                                                             XfTables tb, BigTw bt, int64_t hmask_n, ColsIn ci) {
     using X = XfPow2<L>;
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_cols(const cf *__restrict_
         const int64_t col = (idx % ncolblocks) * C::FPW + grp;
         const int64_t base = (idx / ncolblocks) * os + col;
         cf v[C::R];
-        if (ci.kind == 1) {
+        if constexpr (KIND == 1) {
             const float m1 = ci.mom ? (float)ci.mom[0] : 0.f, m2 = ci.mom ? (float)ci.mom[1] : 0.f;
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
@@ -352,14 +351,6 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_cols(const cf *__restrict_
                 const int64_t ic = ok ? i : 0;
                 const float a = ci.r1[ic], b = ci.r2 ? ci.r2[ic] : m2;
                 v[t] = ok ? mk(a - m1, b - m2) : mk(0.f, 0.f);
-            }
-        } else if (ci.kind == 2) {
-#pragma unroll
-            for (int t = 0; t < C::R; ++t) {
-                const int64_t k = base + (int64_t)(tid + C::T * t) * es;
-                const cf z = ci.Z[k], zm = ci.Z[(ci.L - k) & (ci.L - 1)];
-                const cf zz = cmul(z, zm);
-                v[t] = mk(0.5f * zz.y, -0.25f * (cnorm(z) - cnorm(zm)));
             }
         } else {
 #pragma unroll
@@ -399,7 +390,7 @@ struct RowsOut {
     int64_t n, Ltot;
     const double *mom;
 };
-template <int L>
+template <int L, bool CCF>
 __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restrict__ in, cf *__restrict__ out, int64_t A, int64_t B,
                                                                 int conj_out, float scale, XfTables tb, RowsOut ro) {
     using X = XfPow2<L>;
@@ -416,7 +407,7 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restr
         for (int t = 0; t < C::R; ++t) v[t] = row[tid + C::T * t];
         xf.fwd(v, lds, tid, L);
         const int64_t off = kb * A + ka;
-        if (ro.co != nullptr) {
+        if constexpr (CCF) {
             const float nrm = (float)(ro.mom[2] / (double)ro.Ltot);
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {

@@ -89,7 +89,7 @@ int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_
                        int64_t out_es, int conj_in, int conj_out, float scale, const Xf &xf, BigTw bt);
 int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
                     int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n = 0,
-                    ColsIn ci = ColsIn{0, nullptr, nullptr, nullptr, 0, nullptr, 0});
+                    ColsIn ci = ColsIn{0, nullptr, nullptr, nullptr, 0});
 int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B, int conj_out, float scale, const Xf &xf,
                         RowsOut ro = RowsOut{nullptr, 0, 0, nullptr});
 // elementwise / transpose pieces of the long paths (k_fft.hip)

@@ -404,7 +404,7 @@ bool big_three_pass(int64_t N) {
 
 // fused first-pass input / last-pass output of ONE three-pass transform (see ColsIn / RowsOut in kernels.h)
 struct BigFuse {
-    ColsIn ci = ColsIn{0, nullptr, nullptr, nullptr, 0, nullptr, 0};
+    ColsIn ci = ColsIn{0, nullptr, nullptr, nullptr, 0};
     RowsOut ro = RowsOut{nullptr, 0, 0, nullptr};
 };
 int dev_fft_big_pow2(const cf *in, cf *out, int64_t N, int inverse, int hmask = 0, int64_t batch = 1, const BigFuse *fz = nullptr) {
@@ -1507,7 +1507,7 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
                 // real -> complex pack fused into the first pass of the forward transform (the zero padding is not loaded),
                 // the analytic-signal mask into the first pass of the inverse one
                 BigFuse fz;
-                fz.ci = ColsIn{1, xd + b * x_ld, nullptr, nullptr, nuse, nullptr, 0};
+                fz.ci = ColsIn{1, xd + b * x_ld, nullptr, nullptr, nuse};
                 if (dev_fft_big_pow2(A, A, nfft, 0, 0, 1, &fz)) return -1;
                 if (dev_fft_big_pow2(A, od + b * nfft, nfft, 1, 1)) return -1;
                 continue;
@@ -1647,14 +1647,14 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
         if (g.bigA.ensure(sizeof(cf) * (size_t)L) || g.bigB.ensure(sizeof(cf) * (size_t)L)) return -1;
         cf *A = (cf *)g.bigA.p, *B = (cf *)g.bigB.p;
         if (big_three_pass(L) && !env_flag("SP_LONG_NOFUSE")) {
-            // the three elementwise kernels ride on the transforms: pack in the first pass of the first transform, the
-            // middle step in the first pass of the second, lag re-ordering + real part in its last pass
+            // two of the three elementwise kernels ride on the transforms: the pack in the first pass of the first transform
+            // (the zero half is never loaded), lag re-ordering + real part in the last pass of the second
             BigFuse f1, f2;
-            f1.ci = ColsIn{1, a, b, tb.d + 16, n, nullptr, 0};
+            f1.ci = ColsIn{1, a, b, tb.d + 16, n};
             if (dev_fft_big_pow2(A, B, L, 0, 0, 1, &f1)) return -1;          // B = FFT(z)
-            f2.ci = ColsIn{2, nullptr, nullptr, nullptr, 0, B, L};
+            LAUNCHCHK(launch_xc_mid(lc(), B, L, A));                         // conj(A conj(B)) spectrum
             f2.ro = RowsOut{od, n, L, tb.d + 16};
-            if (dev_fft_big_pow2(B, A, L, 0, 0, 1, &f2)) return -1;          // reads Z = B on the fly, writes co
+            if (dev_fft_big_pow2(A, B, L, 0, 0, 1, &f2)) return -1;          // writes co from its last pass
         } else {
             LAUNCHCHK(launch_xc_pack(lc(), a, b, n, L, tb.d + 16, A));
             if (dev_fft_big_pow2(A, B, L, 0)) return -1;
