@@ -73,10 +73,24 @@ inline RunPart run_partition_2d(int L, int64_t nframes, int ncu, int ny) {
     r.groups = (int64_t)r.blocks * fpw;
     return r;
 }
+// grid of the row kernels (FFT rows, Hilbert rows, FIR block pairs): every workgroup pays a prologue (twiddle constants with
+// 30 divisions per twiddled pass) before its first row, so few, long-lived workgroups win for the long transforms -- measured
+// (tools/capsweep.py, ms): 4096 rows of 4096: 0.088 at 16 blocks per CU, 0.062 at 4, 0.055 at 2; 65536 rows: 0.825 / 0.790 /
+// 0.823; 8192 points: 0.245 / 0.170 / 0.160; 2048 points: 4 per CU wins for 4096 rows (0.039 vs 0.050), 16 for 65536 rows
+// (0.394 vs 0.413); <= 1024 points: no difference.  Rule: 4 per CU from 4096 points up; at 2048 points at least 4 rows per
+// workgroup (not below 2 per CU); 16 per CU otherwise.  SP_STRIDED_CAP overrides it.
 inline int strided_blocks(int L, int64_t items, int ncu) {
+    static const int forced = [] {
+        const char *e = getenv("SP_STRIDED_CAP");
+        return e ? atoi(e) : 0;
+    }();
     const int fpw = fpw_of(L);
     int64_t b = (items + fpw - 1) / fpw;
-    const int64_t cap = (int64_t)ncu * 16;
+    int64_t cap = (int64_t)ncu * (forced > 0 ? forced : (L >= 4096 ? 4 : 16));
+    if (forced <= 0 && L == 2048) {
+        const int64_t q = b / 4;
+        if (q < cap) cap = q > (int64_t)ncu * 2 ? q : (int64_t)ncu * 2;
+    }
     if (b > cap) b = cap;
     if (b < 1) b = 1;
     return (int)b;
