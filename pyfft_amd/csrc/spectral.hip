@@ -1198,8 +1198,11 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     if (nch < 1 || x_ld < nsig) return fail("%s: bad nch / x_ld", who);
     if (detrend < 0 || detrend > 2) return fail("%s: detrend must be 0, 1 or 2", who);
     ApiLock lk;
+    const bool lng = !wg_capable(nfft);          // segments longer than one workgroup transform: spectra by the long path
     Xf xf;
-    if (get_xf(nfft, &xf)) return -1;
+    xf.L = 0;
+    xf.blue = true;
+    if (!lng && get_xf(nfft, &xf)) return -1;
     const int nb = nfft / 2 + 1;
     const float *xd = x;
     if (!mem) {
@@ -1245,6 +1248,10 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
         mc = (nframes + nchunks - 1) / nchunks;
         mc = (mc + 31) & ~(int64_t)31;
     }
+    if (lng) {
+        const int64_t lm = long_chunk_frames(nfft, nframes);
+        if (mc > lm) mc = lm;
+    }
     if (mc > nframes) mc = nframes;
     // contraction on the matrix cores: fused form reading the STFT output as it lies (default), the form with a
     // transposed copy (SP_CSDM_TRANSPOSED=1), or the VALU kernel (SP_CSDM_VALU=1); the last two are kept for A/B tests
@@ -1255,8 +1262,8 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     // fused path: every (channel, frame) row of the spectra starts on a 128-byte line (row pitch padded to a multiple of 16
     // bins).  With the natural pitch nb = nfft/2 + 1 (odd) almost every 16-bin tile row straddled two lines and the
     // contraction fetched 1.9x its algorithmic bytes (calibrated PMC: profiles/r02_fetch_size_calibration.txt)
-    const bool rp_stft = !xf.blue && xf.L >= 32 && nch <= 65535;
-    const int ld = (use_fused && rp_stft && !env_flag("SP_CSDM_NOPAD")) ? (nb + 15) / 16 * 16 : nb;
+    const bool rp_stft = !lng && !xf.blue && xf.L >= 32 && nch <= 65535;
+    const int ld = (use_fused && (rp_stft || lng) && !env_flag("SP_CSDM_NOPAD")) ? (nb + 15) / 16 * 16 : nb;
     const size_t sbytes = sizeof(cf) * (size_t)nch * (size_t)mc * (size_t)ld;
     const size_t tbytes = use_fused ? sizeof(cf) * (size_t)nchp * (size_t)mcp * 16
                                     : (use_mfma ? sizeof(cf) * (size_t)nchp * (size_t)mcp * (size_t)nb : sbytes);
@@ -1266,7 +1273,17 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
         const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
         hipLaunchKernelGGL(k_trend_shift, dim3((nch + 63) / 64), dim3(64), 0, g.stream, tb.f, tb.f + 4 * nch, nch,
                            (double)f0 * (double)hop);
-        if (rp_stft && (m >= 2 || ld != nb)) {
+        if (lng) {
+            // long segments: every channel's frames through pack -> batched long FFT, the rfft half of each row copied into Xs
+            if (g.bigA.ensure(sizeof(cf) * (size_t)m * (size_t)nfft)) return -1;
+            cf *S = (cf *)g.bigA.p;
+            for (int c = 0; c < nch; ++c) {
+                if (long_spectra(xd + (size_t)x_ld * (size_t)c, false, (const float *)win_d, nfft, hop, f0, m, tb.f + 4 * c,
+                                 detrend == 2, 0, S, nullptr))
+                    return -1;
+                LAUNCHCHK(launch_long_stft_out(lc(), S, m, nfft, SP_SIDED_HALF, 1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)ld, 0, ld));
+            }
+        } else if (rp_stft && (m >= 2 || ld != nb)) {
             // all channels in one grid, two real frames per transform
             const RunPart rp = run_partition(xf.L, (m + 1) / 2, g.ncu, 1);
             LAUNCHCHK(launch_stft_rp(lc(), xd + (size_t)f0 * (size_t)hop, (const float *)win_d, hop, m, tb.f + 4 * nch,
@@ -1283,7 +1300,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
             LAUNCHCHK(launch_csdm_fused(lc(), Xs, Xt, nch, m, nb, G, ld));
         } else if (use_mfma) {
             const int64_t mp = (m + 31) / 32 * 32;
-            LAUNCHCHK(launch_csdm_transpose_kgc(lc(), Xs, Xt, nch, nchp, m, mp, nb));
+            LAUNCHCHK(launch_csdm_transpose_kgc(lc(), Xs, Xt, nch, nchp, m, mp, nb));   // (these two forms: ld == nb)
             LAUNCHCHK(launch_csdm_mfma(lc(), Xt, nch, nchp, mp, nb, G));
         } else {
             LAUNCHCHK(launch_csdm_transpose(lc(), Xs, Xt, nch, m, nb));

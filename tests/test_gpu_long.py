@@ -292,3 +292,49 @@ def test_long_many_midsize_frames(P):
         ref += (np.abs(np.fft.fft(win[None, :] * xd[st + idx], axis=-1)) ** 2).sum(axis=0)
     ref /= M
     np.testing.assert_allclose(got, ref, rtol=2e-4, atol=1e-6 * ref.max())
+
+
+def test_long_csd_matrix(P):
+    """full CSD matrix with 9 000-point segments (not a power of two): the spectra come from the long path, the
+    contraction is the same matrix-core kernel as at cfg5"""
+    E = P.engine
+    rng = np.random.default_rng(17)
+    nch, nfft, hop, M = 5, 9000, 4500, 6
+    n = (M - 1) * hop + nfft + 3
+    common = rng.standard_normal(n)
+    x = np.stack([(0.3 + 0.1 * c) * np.roll(common, 2 * c) + rng.standard_normal(n) + 0.2 * c for c in range(nch)]).astype(np.float32)
+    win = O.windows("Hanning", nwins=nfft)
+    got = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+    ref = O.csd_matrix(x.astype(np.float64), win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+    assert got.shape == ref.shape == (nfft // 2 + 1, nch, nch)
+    assert np.max(np.abs(got - ref)) <= 2e-4 * np.abs(ref).max()
+    # Hermitian, real diagonal = the long-path Welch PSD of each channel
+    assert np.max(np.abs(got - np.conj(np.swapaxes(got, 1, 2)))) <= 1e-6 * np.abs(ref).max()
+    p0 = E.welch_psd(x[0], win, hop, M, detrend=True, sided=E.SIDED_RAW, scale=1.0)[:nfft // 2 + 1]
+    np.testing.assert_allclose(got[:, 0, 0].real, p0, rtol=2e-4, atol=1e-6 * p0.max())
+
+
+def test_long_paths_on_device_tensors(P):
+    """mem=1: torch CUDA tensors in, torch tensors out, for the long-segment Welch PSD / CSD / STFT"""
+    import torch
+    E = P.engine
+    rng = np.random.default_rng(23)
+    nfft, hop, M = 20000, 10000, 5
+    n = (M - 1) * hop + nfft
+    x = (rng.standard_normal(n) + 1.0).astype(np.float32)
+    y = (0.5 * np.roll(x, 4) + 0.2 * rng.standard_normal(n)).astype(np.float32)
+    win = O.windows("Hamming", nwins=nfft)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    p_t = E.welch_psd(xt, win, hop, M, detrend=True, sided=E.SIDED_ONE, scale=1.0)
+    p_h = E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_ONE, scale=1.0)
+    assert p_t.is_cuda and p_t.dtype == torch.float64
+    np.testing.assert_allclose(p_t.cpu().numpy(), p_h, rtol=1e-12)
+    a_t = E.welch_csd(xt, yt[None, :], win, hop, M, detrend=True, sided=E.SIDED_ONE, scale=1.0)
+    a_h = E.welch_csd(x, y[None, :], win, hop, M, detrend=True, sided=E.SIDED_ONE, scale=1.0)
+    for t, h in zip(a_t, a_h):
+        assert t.is_cuda
+        np.testing.assert_allclose(t.cpu().numpy(), h, rtol=1e-12, atol=1e-30)
+    s_t, _ = E.stft_frames(xt, win, hop, M, detrend=True, sided=E.SIDED_ONE, amp_scale=1.0)
+    s_h, _ = E.stft_frames(x, win, hop, M, detrend=True, sided=E.SIDED_ONE, amp_scale=1.0)
+    assert s_t.is_cuda and s_t.shape == (M, nfft // 2)
+    np.testing.assert_allclose(s_t.cpu().numpy(), s_h, rtol=0, atol=0)
