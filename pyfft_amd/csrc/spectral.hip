@@ -1285,7 +1285,10 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
             }
         } else if (rp_stft && (m >= 2 || ld != nb)) {
             // all channels in one grid, two real frames per transform
-            const RunPart rp = run_partition(xf.L, (m + 1) / 2, g.ncu, 1);
+            // (channels x groups) workgroups: about 8 per CU in all, so that each amortises its twiddle prologue over a long
+            // run of frame pairs (256 groups per channel = 16 pairs per workgroup paid ~9 % for it); SP_STFT_GPC=1: old rule
+            const RunPart rp = env_flag("SP_STFT_GPC") ? run_partition(xf.L, (m + 1) / 2, g.ncu, 1)
+                                                       : run_partition_2d(xf.L, (m + 1) / 2, g.ncu, nch);
             LAUNCHCHK(launch_stft_rp(lc(), xd + (size_t)f0 * (size_t)hop, (const float *)win_d, hop, m, tb.f + 4 * nch,
                                      detrend == 2, xf, rp, SP_SIDED_HALF, 1.f, 0, Xs, nullptr, nch, x_ld,
                                      (int64_t)m * ld, ld));
