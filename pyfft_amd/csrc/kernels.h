@@ -567,6 +567,10 @@ __global__ __launch_bounds__(X::C::WG) __attribute__((amdgpu_waves_per_eu(2, 2))
 #ifndef SP_W3_TW             /* 1: pass-1 constants from the LDS table (with SP_CARRY_W3) */
 #define SP_W3_TW 1
 #endif
+// SP_EST_IN_KERNEL=1 (default): the one-pass kernel estimates mu0 itself (no k_op_estimate launch)
+#ifndef SP_EST_IN_KERNEL
+#define SP_EST_IN_KERNEL 1
+#endif
 // SP_NT_LOADS=1: the carry kernel's sample loads carry the non-temporal cache policy
 #ifndef SP_NT_LOADS
 #define SP_NT_LOADS 0
@@ -609,7 +613,51 @@ __device__ __forceinline__ void welch_carry_body(
     }
 #pragma unroll
     for (int s = 0; s < SHIFT; ++s) sacc[s] = mk(0.f, 0.f);
-    cf mu = load_trend(trend).m;
+    cf mu;
+    if constexpr (ONEPASS && SP_EST_IN_KERNEL) {
+        // the mean ESTIMATE mu0 of the one-pass detrend, computed by every workgroup for itself from the same 16 runs of WG
+        // samples spread over the frames' span (identical loads and reduction order in every workgroup -> identical mu0;
+        // they hit L2 after the first workgroup): saves the separate k_op_estimate launch (12 us + a launch gap per
+        // step).  Any mu0 gives the exact result (the epilogue corrects with the true mean); workgroup 0 publishes it in
+        // trend[] for the epilogue kernels.
+        const int64_t span = (nframes - 1) * (int64_t)hop + N;
+        const int64_t pitch = span / 16;
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int64_t i = pitch * r + (int64_t)threadIdx.x;
+            i = i < span ? i : span - 1;
+            const cf v = load_sample(x, i, CPLX);
+            sx += v.x;
+            sy += v.y;
+        }
+        sx = wave_sum64(sx);
+        sy = wave_sum64(sy);
+        float *red = reinterpret_cast<float *>(smem);            // before the first transform uses the exchange image
+        if ((threadIdx.x & 63) == 0) {
+            red[2 * (threadIdx.x >> 6)] = sx;
+            red[2 * (threadIdx.x >> 6) + 1] = sy;
+        }
+        __syncthreads();
+        double tx = 0.0, ty = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < C::WG / 64; ++wv) {
+            tx += (double)red[2 * wv];
+            ty += (double)red[2 * wv + 1];
+        }
+        const double cnt = 16.0 * (double)C::WG;
+        mu = mk((float)(tx / cnt), (float)(ty / cnt));
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            float *tw = const_cast<float *>(trend);
+            tw[0] = mu.x;
+            tw[1] = mu.y;
+            tw[2] = 0.f;
+            tw[3] = 0.f;
+        }
+    } else {
+        mu = load_trend(trend).m;
+    }
     // keep the constant in VGPRs: a VALU instruction with an SGPR source issues at half rate on gfx950
     // (tools/ubench/vgpr_bank.hip), and it is subtracted from every arriving sample
     asm volatile("" : "+v"(mu.x), "+v"(mu.y));
@@ -2340,10 +2388,13 @@ static __global__ void k_csdm_mirror(double *__restrict__ G, int nch, int nb, in
 // workgroup per row.  nyq = n/2 (even) or (n+1)/2 (odd): for odd n bin `nyq` is left untouched,
 // exactly as the reference does (Q6).
 // ------------------------------------------------------------------------------------------
+#ifndef SP_HILBERT_WAVES
+#define SP_HILBERT_WAVES 1
+#endif
 // RESP: the spectrum is multiplied by the table H[0:n] instead of the mask (sp_spectral_filter: fft_deriv's
 // wavenumber, fft_analysis.py:1526-1546, or any other frequency response).
 template <class X, bool RESP>
-__global__ __launch_bounds__(X::C::WG) void k_hilbert(const float *__restrict__ x, int64_t n_in, int64_t x_ld,
+__global__ __launch_bounds__(X::C::WG, SP_HILBERT_WAVES) void k_hilbert(const float *__restrict__ x, int64_t n_in, int64_t x_ld,
                                                        int64_t batch, XfTables tb, cf *__restrict__ out,
                                                        const cf *__restrict__ H) {
     SP_KERNEL_PROLOGUE(X)

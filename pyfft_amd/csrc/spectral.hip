@@ -638,7 +638,11 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     float *partial = (float *)g.work.p;
     double *est = moments_scratch();
     if (!est) return -1;
+#if !SP_EST_IN_KERNEL
     LAUNCHCHK(launch_op_estimate(lc(), xd, cplx, nsig, est, tb.f));
+#else
+    (void)est;                       // the main kernel estimates mu0 itself and publishes it in tb.f
+#endif
     {
         ProfScope ps;
         LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,
