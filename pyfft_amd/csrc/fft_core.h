@@ -516,6 +516,24 @@ template <int N, bool TW1LDS = false> struct WgFft {
         }
     }
 
+    // constants of ONE twiddled radix-16 pass P >= 1 (wave-specialised callers keep only their own pass's set)
+    template <int P> __device__ __forceinline__ void load_tw_one(const cf *__restrict__ table, int tid) {
+        static_assert(P >= 1 && P < NP && PL::radix(P) == 16, "a twiddled radix-16 pass");
+        constexpr int NS = PL::ns(P);
+        const int e = (tid % NS) * (N / (NS * 16));
+        cf wv[15];
+#pragma unroll
+        for (int s = 1; s < 16; ++s) wv[s - 1] = table[e * s];
+#if SP_PACKED
+        Tw16 w1;
+        make_tw16(w1, wv);
+        pack_tw16(t16[P - 1], w1);
+        k16 = make_k16p();
+#else
+        make_tw16(t16[P - 1], wv);
+#endif
+    }
+
     // physical LDS index of logical element i for exchange number E (0 = first)
     template <int E> static __device__ __forceinline__ int phys(int i) {
         if constexpr (E == 0) return (i % PL::radix(0)) * PL::PITCH1 + i / PL::radix(0);

@@ -1,0 +1,304 @@
+// k_welch_pipe.hip -- the metric shape of the one-pass Welch PSD as a three-stage pipeline of specialised waves.
+//
+// k_welch_carry (kernels.h) gives every wave the whole frame: 601 VALU instructions issued at the single-wave rate, two LDS
+// exchanges, 205 VGPRs = 2 waves per SIMD, and the SIMD's VALU pipe idles whenever one of its two waves is exchanging
+// (DESIGN.md section 4).  Here a workgroup is 12 waves = 3 roles x 4 waves, one wave of each role per SIMD, and a frame
+// moves through the roles in three consecutive periods:
+//   role 0 (front):  stream the hop's new samples (overlap carried in registers, one frame prefetched), detrend by mu0,
+//                    block sums of the one-pass mean correction, window, radix-16 pass 0, scatter into image A[p & 1]
+//   role 1 (middle): gather A (into registers, one period ahead of use), twiddled radix-16 pass 1, scatter into image B
+//   role 2 (back):   gather B (one period ahead of use), twiddled radix-16 pass 2, |X|^2 accumulated in 16 registers
+// with ONE workgroup barrier per period (both images double-buffered: 4 x 32.1 KiB of LDS, one workgroup per CU).  Each
+// role keeps only its own constants (<= 128 VGPRs), the three waves of a SIMD issue VALU concurrently, and the LDS traffic
+// per frame is that of the plain kernel (128 KiB).  Results are bit-identical to k_welch_carry's per group of frames
+// (same arithmetic in the same order per frame; the partition into groups differs).
+// Reference path: fft_analysis.py:2126-2203 fft_win -> :1946 Pstft -> :1980 averagewins.
+#include "launch.h"
+// SP_PIPE_ES=1: the 16 scatter stores of a pass leave 4 at a time behind the radix-4 butterfly that produces them
+#ifndef SP_PIPE_ES
+#define SP_PIPE_ES 1
+#endif
+// SP_PIPE_AHEAD: the front role loads the new samples 1 or 2 frames ahead of use
+#ifndef SP_PIPE_TIMING
+#define SP_PIPE_TIMING 0
+#endif
+// SP_PIPE_PRIO=abc: s_setprio of the front / middle / back role (0 = leave the default)
+#ifndef SP_PIPE_PRIO
+#define SP_PIPE_PRIO 0
+#endif
+#ifndef SP_PIPE_AHEAD
+#define SP_PIPE_AHEAD 1
+#endif
+namespace sp {
+
+#if !SP_PACKED
+template <bool CPLX, int SHIFT>
+__global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, const float *__restrict__ win,
+                                                     int64_t nframes, int64_t fpg, float *__restrict__ trend, XfTables tb,
+                                                     float *__restrict__ partial, cf *__restrict__ spartial) {
+    constexpr int N = 4096;
+    using PL = FftPlan<N>;
+    using F = WgFft<N>;
+    constexpr int T = PL::T, R = PL::R, KEEP = R - SHIFT, IMG = PL::LDS_ELEMS;
+    static_assert(T == 256 && R == 16 && PL::NP == 3, "three radix-16 passes over 256 threads");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *smem = reinterpret_cast<cf *>(smem_raw);
+    cf *imgA = smem, *imgB = smem + 2 * IMG;
+    const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+    const int tid = (int)threadIdx.x & 255;
+    const int hop = SHIFT * T;
+
+    // mu0: the same 16 runs of 256 samples in every workgroup (identical order -> identical value everywhere); any value
+    // gives the exact result, the epilogue corrects with the true mean.  Workgroup 0 publishes it for the epilogue kernels.
+    cf mu;
+    {
+        const int64_t span = (nframes - 1) * (int64_t)hop + N;
+        const int64_t pitch = span / 16;
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int64_t i = pitch * r + (int64_t)tid;
+            i = i < span ? i : span - 1;
+            const cf v = load_sample(x, i, CPLX);
+            sx += v.x;
+            sy += v.y;
+        }
+        sx = wave_sum64(sx);
+        sy = wave_sum64(sy);
+        float *red = reinterpret_cast<float *>(smem);
+        if (role == 0 && (tid & 63) == 0) {
+            red[2 * (tid >> 6)] = sx;
+            red[2 * (tid >> 6) + 1] = sy;
+        }
+        __syncthreads();
+        double tx = 0.0, ty = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+            tx += (double)red[2 * wv];
+            ty += (double)red[2 * wv + 1];
+        }
+        mu = mk((float)(tx / (16.0 * T)), (float)(ty / (16.0 * T)));
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            trend[0] = mu.x;
+            trend[1] = mu.y;
+            trend[2] = 0.f;
+            trend[3] = 0.f;
+        }
+    }
+    const int64_t gid = blockIdx.x;
+    const int64_t g0 = gid * fpg;
+    const int64_t last = nframes - 1;
+    int64_t trips = nframes - g0;
+    trips = trips < 0 ? 0 : (trips > fpg ? fpg : trips);
+#if SP_PIPE_TIMING
+    // diagnostic: per role, cycles between leaving a barrier and arriving at the next one (busy) and cycles spent at the barrier
+    unsigned long long t_busy = 0, t_wait = 0, t_mark = __builtin_amdgcn_s_memtime();
+#define PIPE_SYNC()                                                                                   \
+    {                                                                                                 \
+        const unsigned long long ta_ = __builtin_amdgcn_s_memtime();                                  \
+        __syncthreads();                                                                              \
+        const unsigned long long tb_ = __builtin_amdgcn_s_memtime();                                  \
+        t_busy += ta_ - t_mark;                                                                       \
+        t_wait += tb_ - ta_;                                                                          \
+        t_mark = tb_;                                                                                 \
+    }
+#else
+#define PIPE_SYNC() __syncthreads()
+#endif
+    constexpr int DRAIN = 4;                 // a frame leaves the pipeline 4 periods after it entered
+    const int64_t periods = trips + DRAIN;
+    F f;
+
+    if (role == 0) {
+        if constexpr (SP_PIPE_PRIO) __builtin_amdgcn_s_setprio((SP_PIPE_PRIO / 100) % 10);
+        // keep the constant in VGPRs (an SGPR source halves the VALU issue rate on gfx950)
+        asm volatile("" : "+v"(mu.x), "+v"(mu.y));
+        float w[R];
+        cf sacc[SHIFT], raw[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) w[t] = win[tid + T * t];
+#pragma unroll
+        for (int s = 0; s < SHIFT; ++s) sacc[s] = mk(0.f, 0.f);
+        {
+            const int64_t base = (g0 < nframes ? g0 : last) * hop + tid;
+#pragma unroll
+            for (int t = 0; t < R; ++t) raw[t] = load_sample(x, base + T * t, CPLX) - mu;
+        }
+        // new slots of frame g0 + q (clamped at the end of the signal; unused then): scalar base + lane offset
+        auto issue = [&](cf (&dst)[SHIFT], int64_t q) __attribute__((always_inline)) {
+            const int64_t gq = g0 + q;
+            const int64_t gn = gq < nframes ? gq : last;
+            const int64_t ubase = gn * hop + (int64_t)T * KEEP;
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) {
+                const unsigned off = (unsigned)(tid + T * s);
+                if constexpr (SP_ABLATE & 8) {          // diagnostic: no global loads in the loop
+                    dst[s] = raw[s] + mu;
+                    continue;
+                }
+                if (CPLX) dst[s] = (reinterpret_cast<const cf *>(x) + ubase)[off];
+                else dst[s] = mk((reinterpret_cast<const float *>(x) + ubase)[off], 0.f);
+            }
+        };
+        // one period: loads of frame i + AHEAD go out first and are consumed AHEAD periods later (`fill`); `take` holds the
+        // new slots of frame i + 1
+        auto frame = [&](int64_t i, cf *img, cf (&fill)[SHIFT], cf (&take)[SHIFT]) __attribute__((always_inline)) {
+            issue(fill, i + SP_PIPE_AHEAD);
+            __builtin_amdgcn_sched_barrier(0);          // keep the loads above the arithmetic (hipcc sank them to the barrier)
+            cf v[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = w[t] * raw[t];
+#if SP_PIPE_ES && !SP_ABLATE
+            f.template bfly_scatter<0>(v, img, tid);
+#else
+            f.template bfly<0>(v, tid);
+            if constexpr (!(SP_ABLATE & 2)) f.template scatter<0>(v, img, tid);
+            else asm volatile("" ::"v"(v[0].x), "v"(v[5].y), "v"(v[10].x), "v"(v[15].y));
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            // off the critical path of the period: the stores above drain while these issue
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) sacc[s] = sacc[s] + raw[KEEP + s];
+#pragma unroll
+            for (int t = 0; t < KEEP; ++t) raw[t] = raw[t + SHIFT];
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) raw[KEEP + s] = take[s] - mu;
+        };
+        int64_t i = 0;
+#if SP_PIPE_AHEAD == 2
+        cf nxa[SHIFT], nxb[SHIFT];
+        issue(nxa, 1);
+        for (; i + 1 < trips; i += 2) {
+            frame(i, imgA, nxb, nxa);
+            PIPE_SYNC();
+            frame(i + 1, imgA + IMG, nxa, nxb);
+            PIPE_SYNC();
+        }
+        if (i < trips) {
+            frame(i, imgA, nxb, nxa);
+            PIPE_SYNC();
+        }
+#else
+        for (; i + 1 < trips; i += 2) {
+            cf nx0[SHIFT], nx1[SHIFT];
+            frame(i, imgA, nx0, nx0);
+            PIPE_SYNC();
+            frame(i + 1, imgA + IMG, nx1, nx1);
+            PIPE_SYNC();
+        }
+        if (i < trips) {
+            cf nx0[SHIFT];
+            frame(i, imgA, nx0, nx0);
+            PIPE_SYNC();
+        }
+#endif
+#pragma unroll
+        for (int d = 0; d < DRAIN; ++d) PIPE_SYNC();
+#pragma unroll
+        for (int s = 0; s < SHIFT; ++s) spartial[gid * hop + tid + T * s] = sacc[s];
+    } else if (role == 1) {
+        if constexpr (SP_PIPE_PRIO) __builtin_amdgcn_s_setprio((SP_PIPE_PRIO / 10) % 10);
+        // period p: the gather of frame p-1 is ISSUED first and lands while the butterflies of frame p-2 (gathered one period
+        // earlier into the other register set) run -- no wave starts a period by waiting for the LDS pipe
+        f.template load_tw_one<1>(tb.tw, tid);
+        cf va[R], vb[R];
+        auto step = [&](cf (&fill)[R], cf (&use)[R], int64_t p, const cf *src, cf *dst) __attribute__((always_inline)) {
+            if (p >= 1 && p <= trips) {
+                if constexpr (!(SP_ABLATE & 2)) f.template gather<0>(fill, src, tid);
+                else {
+#pragma unroll
+                    for (int t = 0; t < R; ++t) fill[t] = mk(use[t].y + 1.f, use[t].x);
+                }
+            }
+            if (p >= 2 && p <= trips + 1) {
+#if SP_PIPE_ES && !SP_ABLATE
+                f.template bfly_scatter<1>(use, dst, tid);
+#else
+                f.template bfly<1>(use, tid);
+                if constexpr (!(SP_ABLATE & 2)) f.template scatter<1>(use, dst, tid);
+                else asm volatile("" ::"v"(use[0].x), "v"(use[5].y), "v"(use[10].x), "v"(use[15].y));
+#endif
+            }
+            PIPE_SYNC();
+        };
+        for (int64_t p = 0; p < periods; p += 2) {
+            step(va, vb, p, imgA + IMG, imgB);
+            if (p + 1 < periods) step(vb, va, p + 1, imgA, imgB + IMG);
+        }
+    } else {
+        if constexpr (SP_PIPE_PRIO) __builtin_amdgcn_s_setprio(SP_PIPE_PRIO % 10);
+        f.template load_tw_one<2>(tb.tw, tid);
+        float acc[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) acc[t] = 0.f;
+        cf va[R], vb[R];
+        auto step = [&](cf (&fill)[R], cf (&use)[R], int64_t p, const cf *src) __attribute__((always_inline)) {
+            if (p >= 3 && p <= trips + 2) {
+                if constexpr (!(SP_ABLATE & 2)) f.template gather<1>(fill, src, tid);
+                else {
+#pragma unroll
+                    for (int t = 0; t < R; ++t) fill[t] = mk(use[t].y + 1.f, use[t].x);
+                }
+            }
+            if (p >= 4 && p <= trips + 3) {
+                f.template bfly<2>(use, tid);
+#pragma unroll
+                for (int t = 0; t < R; ++t) acc[t] = fmaf(use[t].y, use[t].y, fmaf(use[t].x, use[t].x, acc[t]));
+            }
+            PIPE_SYNC();
+        };
+        for (int64_t p = 0; p < periods; p += 2) {
+            step(va, vb, p, imgB + IMG);
+            if (p + 1 < periods) step(vb, va, p + 1, imgB);
+        }
+#pragma unroll
+        for (int t = 0; t < R; ++t) partial[gid * N + tid + T * t] = acc[t];
+    }
+#if SP_PIPE_TIMING
+    if ((blockIdx.x == 3 || blockIdx.x == 200) && tid == 0)
+        printf("block %d role %d: busy %llu wait %llu cycles over %lld periods\n", (int)blockIdx.x, role, t_busy, t_wait, (long long)periods);
+#endif
+#undef PIPE_SYNC
+}
+#endif
+
+bool welch_pipe_eligible(const Xf &xf, int hop) {
+#if SP_PACKED
+    (void)xf;
+    (void)hop;
+    return false;
+#else
+    return !xf.blue && xf.L == 4096 && (hop == 2048 || hop == 1024 || hop == 4096);
+#endif
+}
+
+int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, float *trend,
+                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial) {
+#if SP_PACKED
+    return -1;
+#else
+    const size_t lds = sizeof(cf) * 4 * (size_t)FftPlan<4096>::LDS_ELEMS;
+#define PIPE_(CP, S)                                                                                  \
+    {                                                                                                 \
+        static bool once = false;                                                                     \
+        if (!once) {                                                                                  \
+            if (hipFuncSetAttribute((const void *)k_welch_pipe<CP, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+                return -1;                                                                            \
+            once = true;                                                                              \
+        }                                                                                             \
+        hipLaunchKernelGGL((k_welch_pipe<CP, S>), dim3(rp.blocks), dim3(768), lds, c.stream, x, win, nframes, rp.fpg, trend, \
+                           xf.tb, partial, spartial);                                                 \
+    }
+    const int shift = hop / 256;
+    if (cplx) {
+        if (shift == 8) PIPE_(true, 8) else if (shift == 4) PIPE_(true, 4) else PIPE_(true, 16)
+    } else {
+        if (shift == 8) PIPE_(false, 8) else if (shift == 4) PIPE_(false, 4) else PIPE_(false, 16)
+    }
+#undef PIPE_
+    return 0;
+#endif
+}
+
+}   // namespace sp

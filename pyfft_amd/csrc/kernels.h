@@ -571,6 +571,10 @@ __global__ __launch_bounds__(X::C::WG) __attribute__((amdgpu_waves_per_eu(2, 2))
 #ifndef SP_EST_IN_KERNEL
 #define SP_EST_IN_KERNEL 1
 #endif
+// SP_WELCH_PIPE_DEFAULT: 1 = nfft 4096 one-pass Welch goes through k_welch_pipe (k_welch_pipe.hip); SP_WELCH_PIPE=0/1 overrides at run time
+#ifndef SP_WELCH_PIPE_DEFAULT
+#define SP_WELCH_PIPE_DEFAULT 1
+#endif
 // SP_NT_LOADS=1: the carry kernel's sample loads carry the non-temporal cache policy
 #ifndef SP_NT_LOADS
 #define SP_NT_LOADS 0

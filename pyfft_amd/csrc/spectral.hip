@@ -619,7 +619,20 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     // its own trend record: calls between sp_welch_accum and sp_welch_finish reuse the shared one
     if (g.pend_trend.ensure(256)) return -1;
     TrendBuf tb{(float *)g.pend_trend.p, nullptr};
-    const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+    // the metric shape runs as a pipeline of specialised waves (k_welch_pipe.hip): one 768-thread workgroup per CU
+    static const int pipe_mode = [] {
+        const char *e = getenv("SP_WELCH_PIPE");
+        return e ? atoi(e) : SP_WELCH_PIPE_DEFAULT;
+    }();
+    static const int pipe_gpc = [] {
+        const char *e = getenv("SP_PIPE_GPC");
+        const int k = e ? atoi(e) : 0;
+        return k > 0 ? k : 1;
+    }();
+    // (the pipeline spends 4 periods per workgroup filling and draining: from 32 frames per CU on; SP_WELCH_PIPE=2 forces
+    //  it for any frame count -- the tests' way to reach its tail handling at small sizes)
+    const bool pipe = welch_pipe_eligible(xf, hop) && (pipe_mode >= 2 || (pipe_mode == 1 && nframes >= 32 * (int64_t)g.ncu));
+    const RunPart rp = pipe ? run_partition(xf.L, nframes, g.ncu, pipe_gpc) : run_partition(xf.L, nframes, g.ncu);
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
     const size_t sp_bytes = sizeof(cf) * (size_t)rp.groups * (size_t)hop;
     const size_t st_doubles = (size_t)nfft + 2 * (size_t)hop + 8;
@@ -639,11 +652,15 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     double *est = moments_scratch();
     if (!est) return -1;
 #if !SP_EST_IN_KERNEL
-    LAUNCHCHK(launch_op_estimate(lc(), xd, cplx, nsig, est, tb.f));
+    if (!pipe) LAUNCHCHK(launch_op_estimate(lc(), xd, cplx, nsig, est, tb.f));
 #else
     (void)est;                       // the main kernel estimates mu0 itself and publishes it in tb.f
 #endif
-    {
+    if (pipe) {
+        ProfScope ps;
+        LAUNCHCHK(launch_welch_pipe(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, spartial));
+        g.last_kernel = "k_welch_pipe(onepass)";
+    } else {
         ProfScope ps;
         LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,
                                spartial, &g.last_kernel));

@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--real", action="store_true")
     ap.add_argument("--ov", type=float, default=0.5)
-    ap.add_argument("--check", action="store_true", help="parity of the first 2^20 samples against the CPU oracle first")
+    ap.add_argument("--check", action="store_true", help="parity of the first 2^check_log2n samples against the CPU oracle first")
+    ap.add_argument("--check-log2n", type=int, default=20)
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
     n = 1 << a.log2n
@@ -38,7 +39,7 @@ def main():
     win = windows("Hanning", nwins=nfft, verbose=False)
     if a.check:
         from oracle import cpu_ref as O
-        nc = min(n, 1 << 20)
+        nc = min(n, 1 << a.check_log2n)
         Mc = (nc - nfft) // hop + 1
         xc = x[:nc].cpu().numpy()
         for detrend in (True, False):
