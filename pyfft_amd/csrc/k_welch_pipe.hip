@@ -19,6 +19,10 @@
 #define SP_PIPE_ES 1
 #endif
 // SP_PIPE_AHEAD: the front role loads the new samples 1 or 2 frames ahead of use
+// SP_PIPE_SPREAD=1 (with SP_PIPE_AHEAD=2): the front role issues its loads in four groups spread over the period
+#ifndef SP_PIPE_SPREAD
+#define SP_PIPE_SPREAD 0
+#endif
 #ifndef SP_PIPE_TIMING
 #define SP_PIPE_TIMING 0
 #endif
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
     trips = trips < 0 ? 0 : (trips > fpg ? fpg : trips);
 #if SP_PIPE_TIMING
     // diagnostic: per role, cycles between leaving a barrier and arriving at the next one (busy) and cycles spent at the barrier
-    unsigned long long t_busy = 0, t_wait = 0, t_mark = __builtin_amdgcn_s_memtime();
+    unsigned long long t_busy = 0, t_wait = 0, t_issue = 0, t_mark = __builtin_amdgcn_s_memtime();
 #define PIPE_SYNC()                                                                                   \
     {                                                                                                 \
         const unsigned long long ta_ = __builtin_amdgcn_s_memtime();                                  \
@@ -126,12 +130,14 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
             for (int t = 0; t < R; ++t) raw[t] = load_sample(x, base + T * t, CPLX) - mu;
         }
         // new slots of frame g0 + q (clamped at the end of the signal; unused then): scalar base + lane offset
-        auto issue = [&](cf (&dst)[SHIFT], int64_t q) __attribute__((always_inline)) {
+        // slots [s0, s1) of the new samples of frame g0 + q
+        auto issue_part = [&](cf (&dst)[SHIFT], int64_t q, int s0, int s1) __attribute__((always_inline)) {
             const int64_t gq = g0 + q;
-            const int64_t gn = gq < nframes ? gq : last;
+            int64_t gn = gq < nframes ? gq : last;
+            if constexpr (SP_ABLATE & 16) gn = (blockIdx.x & 7) + (q & 1);          // diagnostic: every load hits L2
             const int64_t ubase = gn * hop + (int64_t)T * KEEP;
 #pragma unroll
-            for (int s = 0; s < SHIFT; ++s) {
+            for (int s = s0; s < s1; ++s) {
                 const unsigned off = (unsigned)(tid + T * s);
                 if constexpr (SP_ABLATE & 8) {          // diagnostic: no global loads in the loop
                     dst[s] = raw[s] + mu;
@@ -141,15 +147,40 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
                 else dst[s] = mk((reinterpret_cast<const float *>(x) + ubase)[off], 0.f);
             }
         };
+        auto issue = [&](cf (&dst)[SHIFT], int64_t q) __attribute__((always_inline)) { issue_part(dst, q, 0, SHIFT); };
         // one period: loads of frame i + AHEAD go out first and are consumed AHEAD periods later (`fill`); `take` holds the
         // new slots of frame i + 1
         auto frame = [&](int64_t i, cf *img, cf (&fill)[SHIFT], cf (&take)[SHIFT]) __attribute__((always_inline)) {
+#if SP_PIPE_TIMING
+            const unsigned long long ti0_ = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#if SP_PIPE_SPREAD
+            issue_part(fill, i + SP_PIPE_AHEAD, 0, SHIFT / 4);
+#else
             issue(fill, i + SP_PIPE_AHEAD);
+#endif
             __builtin_amdgcn_sched_barrier(0);          // keep the loads above the arithmetic (hipcc sank them to the barrier)
+#if SP_PIPE_TIMING
+            t_issue += __builtin_amdgcn_s_memtime() - ti0_;
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             cf v[R];
 #pragma unroll
             for (int t = 0; t < R; ++t) v[t] = w[t] * raw[t];
-#if SP_PIPE_ES && !SP_ABLATE
+#if SP_PIPE_SPREAD
+            // the other three quarters of the loads leave behind the store groups of the butterfly: a CU keeps about
+            // 24-32 KiB of misses in flight (tools/ubench/stream_mlp.hip) and HBM latency is about one period, so a burst of
+            // 16 KiB at the top of a period blocks at issue (350 cycles per period measured) while the same loads spread
+            // over the period find the queue drained
+            {
+                auto store = [&](int k, cf val) __attribute__((always_inline)) {
+                    img[F::template phys<0>(tid * 16 + k)] = val;
+                    if (k >= 12 && k < 15) issue_part(fill, i + SP_PIPE_AHEAD, (k - 11) * (SHIFT / 4), (k - 10) * (SHIFT / 4));
+                };
+                dft16s_es<false>(v, f.t16[0], store);
+            }
+#elif SP_PIPE_ES && !SP_ABLATE
             f.template bfly_scatter<0>(v, img, tid);
 #else
             f.template bfly<0>(v, tid);
@@ -257,7 +288,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
     }
 #if SP_PIPE_TIMING
     if ((blockIdx.x == 3 || blockIdx.x == 200) && tid == 0)
-        printf("block %d role %d: busy %llu wait %llu cycles over %lld periods\n", (int)blockIdx.x, role, t_busy, t_wait, (long long)periods);
+        printf("block %d role %d: busy %llu wait %llu issue %llu cycles over %lld periods\n", (int)blockIdx.x, role, t_busy, t_wait, t_issue, (long long)periods);
 #endif
 #undef PIPE_SYNC
 }
