@@ -39,7 +39,7 @@ from pyfft_amd.windows import windows      # noqa: E402
 from pyfft_amd.dist import shard_plan, WelchPipeline   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
-PMC_RECORD = os.path.join(ROOT, "profiles", "pmc_welch_carry_current.json")
+PMC_RECORD = os.path.join(ROOT, "profiles", "pmc_metric_kernel_current.json")
 
 
 def kernel_source_digest():
@@ -242,7 +242,7 @@ def main():
                      "kernel": "%s<%d,complex64>" % (E.profile_last_kernel(), nfft),
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "VALU + LDS co-bound (ablation table, DESIGN.md); traffic = rocprofv3 PMC bytes of this build "
-                             "(profiles/pmc_welch_carry_current.json) or null"},
+                             "(profiles/pmc_metric_kernel_current.json) or null"},
     }
 
     if rank == 0 and world == 1 and args.cpu_log2n > 0:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/pmc_record.py <dir> <kernel substring> <fetch correction>: mean FETCH_SIZE / WRITE_SIZE per dispatch of the metric
-kernel -> profiles/pmc_welch_carry_current.json, tied to the kernel sources by their sha256 (bench.py reads it back and
+kernel -> profiles/pmc_metric_kernel_current.json, tied to the kernel sources by their sha256 (bench.py reads it back and
 reports roofline.traffic only when the digest matches the build it runs)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
@@ -37,6 +37,6 @@ rec = {"kernel": pat, "log2n": 28, "nfft": 4096, "fetch_size_kib": fetch, "write
        "dispatches": len(vals["FETCH_SIZE"]), "source_sha256": h.hexdigest(),
        "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 tools/kbench.py; FETCH_SIZE x "
               "correction for 8 B/lane coalesced loads as calibrated by tools/pmc_calib.sh (profiles/r02_fetch_size_calibration.txt)"}
-with open(os.path.join(ROOT, "profiles", "pmc_welch_carry_current.json"), "w") as f:
+with open(os.path.join(ROOT, "profiles", "pmc_metric_kernel_current.json"), "w") as f:
     json.dump(rec, f, indent=1)
 print(json.dumps(rec, indent=1))
