@@ -36,7 +36,7 @@
 namespace sp {
 
 #if !SP_PACKED
-template <bool CPLX, int SHIFT>
+template <bool CPLX, int SHIFT, bool ONEPASS>
 __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, const float *__restrict__ win,
                                                      int64_t nframes, int64_t fpg, float *__restrict__ trend, XfTables tb,
                                                      float *__restrict__ partial, cf *__restrict__ spartial) {
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
     // mu0: the same 16 runs of 256 samples in every workgroup (identical order -> identical value everywhere); any value
     // gives the exact result, the epilogue corrects with the true mean.  Workgroup 0 publishes it for the epilogue kernels.
     cf mu;
-    {
+    if constexpr (ONEPASS) {
         const int64_t span = (nframes - 1) * (int64_t)hop + N;
         const int64_t pitch = span / 16;
         float sx = 0.f, sy = 0.f;
@@ -89,6 +89,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
             trend[2] = 0.f;
             trend[3] = 0.f;
         }
+    } else {
+        mu = load_trend(trend).m;          // the caller's constant (or zero): plain accumulation, no epilogue
     }
     const int64_t gid = blockIdx.x;
     const int64_t g0 = gid * fpg;
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
             __builtin_amdgcn_sched_barrier(0);
             // off the critical path of the period: the stores above drain while these issue
 #pragma unroll
-            for (int s = 0; s < SHIFT; ++s) sacc[s] = sacc[s] + raw[KEEP + s];
+            for (int s = 0; s < SHIFT; ++s)
+                if constexpr (ONEPASS) sacc[s] = sacc[s] + raw[KEEP + s];
 #pragma unroll
             for (int t = 0; t < KEEP; ++t) raw[t] = raw[t + SHIFT];
 #pragma unroll
@@ -227,7 +230,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
 #pragma unroll
         for (int d = 0; d < DRAIN; ++d) PIPE_SYNC();
 #pragma unroll
-        for (int s = 0; s < SHIFT; ++s) spartial[gid * hop + tid + T * s] = sacc[s];
+        for (int s = 0; s < SHIFT; ++s)
+            if constexpr (ONEPASS) spartial[gid * hop + tid + T * s] = sacc[s];
     } else if (role == 1) {
         if constexpr (SP_PIPE_PRIO) __builtin_amdgcn_s_setprio((SP_PIPE_PRIO / 10) % 10);
         // period p: the gather of frame p-1 is ISSUED first and lands while the butterflies of frame p-2 (gathered one period
@@ -310,23 +314,26 @@ int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, i
     return -1;
 #else
     const size_t lds = sizeof(cf) * 4 * (size_t)FftPlan<4096>::LDS_ELEMS;
-#define PIPE_(CP, S)                                                                                  \
+#define PIPE_(CP, S, OP)                                                                                  \
     {                                                                                                 \
         static bool once = false;                                                                     \
         if (!once) {                                                                                  \
-            if (hipFuncSetAttribute((const void *)k_welch_pipe<CP, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            if (hipFuncSetAttribute((const void *)k_welch_pipe<CP, S, OP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
                 return -1;                                                                            \
             once = true;                                                                              \
         }                                                                                             \
-        hipLaunchKernelGGL((k_welch_pipe<CP, S>), dim3(rp.blocks), dim3(768), lds, c.stream, x, win, nframes, rp.fpg, trend, \
+        hipLaunchKernelGGL((k_welch_pipe<CP, S, OP>), dim3(rp.blocks), dim3(768), lds, c.stream, x, win, nframes, rp.fpg, trend, \
                            xf.tb, partial, spartial);                                                 \
     }
     const int shift = hop / 256;
-    if (cplx) {
-        if (shift == 8) PIPE_(true, 8) else if (shift == 4) PIPE_(true, 4) else PIPE_(true, 16)
+#define PIPE_S_(CP, OP)                                                                               \
+    if (shift == 8) PIPE_(CP, 8, OP) else if (shift == 4) PIPE_(CP, 4, OP) else PIPE_(CP, 16, OP)
+    if (spartial) {
+        if (cplx) { PIPE_S_(true, true) } else { PIPE_S_(false, true) }
     } else {
-        if (shift == 8) PIPE_(false, 8) else if (shift == 4) PIPE_(false, 4) else PIPE_(false, 16)
+        if (cplx) { PIPE_S_(true, false) } else { PIPE_S_(false, false) }
     }
+#undef PIPE_S_
 #undef PIPE_
     return 0;
 #endif

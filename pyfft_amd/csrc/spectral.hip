@@ -602,6 +602,25 @@ int get_window_spectrum(const float *win, int nfft, const Xf &xf, void **Wf_d) {
     return 0;
 }
 
+// the nfft-4096 Welch shapes run as a pipeline of specialised waves (k_welch_pipe.hip): one 768-thread workgroup per CU.
+// The pipeline spends 4 periods per workgroup filling and draining: taken from 32 frames per CU on; SP_WELCH_PIPE=0 turns it
+// off, 2 forces it for any frame count (the tests' way to reach its tail handling at small sizes).
+static int welch_pipe_gpc() {
+    static const int v = [] {
+        const char *e = getenv("SP_PIPE_GPC");
+        const int k = e ? atoi(e) : 0;
+        return k > 0 ? k : 1;
+    }();
+    return v;
+}
+static bool welch_pipe_wanted(const Xf &xf, int hop, int64_t nframes) {
+    static const int mode = [] {
+        const char *e = getenv("SP_WELCH_PIPE");
+        return e ? atoi(e) : SP_WELCH_PIPE_DEFAULT;
+    }();
+    return welch_pipe_eligible(xf, hop) && (mode >= 2 || (mode == 1 && nframes >= 32 * (int64_t)g.ncu));
+}
+
 // want_sum: also produce the shard's plain sample sum (split ABI, one more tiny launch); without it the finish kernel
 // derives the shard mean itself
 int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
@@ -619,20 +638,8 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     // its own trend record: calls between sp_welch_accum and sp_welch_finish reuse the shared one
     if (g.pend_trend.ensure(256)) return -1;
     TrendBuf tb{(float *)g.pend_trend.p, nullptr};
-    // the metric shape runs as a pipeline of specialised waves (k_welch_pipe.hip): one 768-thread workgroup per CU
-    static const int pipe_mode = [] {
-        const char *e = getenv("SP_WELCH_PIPE");
-        return e ? atoi(e) : SP_WELCH_PIPE_DEFAULT;
-    }();
-    static const int pipe_gpc = [] {
-        const char *e = getenv("SP_PIPE_GPC");
-        const int k = e ? atoi(e) : 0;
-        return k > 0 ? k : 1;
-    }();
-    // (the pipeline spends 4 periods per workgroup filling and draining: from 32 frames per CU on; SP_WELCH_PIPE=2 forces
-    //  it for any frame count -- the tests' way to reach its tail handling at small sizes)
-    const bool pipe = welch_pipe_eligible(xf, hop) && (pipe_mode >= 2 || (pipe_mode == 1 && nframes >= 32 * (int64_t)g.ncu));
-    const RunPart rp = pipe ? run_partition(xf.L, nframes, g.ncu, pipe_gpc) : run_partition(xf.L, nframes, g.ncu);
+    const bool pipe = welch_pipe_wanted(xf, hop, nframes);
+    const RunPart rp = pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc()) : run_partition(xf.L, nframes, g.ncu);
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
     const size_t sp_bytes = sizeof(cf) * (size_t)rp.groups * (size_t)hop;
     const size_t st_doubles = (size_t)nfft + 2 * (size_t)hop + 8;
@@ -936,7 +943,9 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         if (get_trendbuf(1, &tb)) return -1;
         if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
         const bool pair = !cplx && nframes >= 2 && !segmean && !env_flag("SP_NO_REALPAIR");
-        const RunPart rp = run_partition(xf.L, pair ? (nframes + 1) / 2 : nframes, g.ncu);
+        const bool pipe = !pair && !segmean && detrend != 2 && allow_carry && welch_pipe_wanted(xf, hop, nframes);
+        const RunPart rp = pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc())
+                                : run_partition(xf.L, pair ? (nframes + 1) / 2 : nframes, g.ncu);
         if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
         float *partial = (float *)g.work.p;
         {
@@ -946,6 +955,9 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
                 LAUNCHCHK(launch_welch_rp(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf,
                                           partial, rp));
                 g.last_kernel = "k_welch_rp";
+            } else if (pipe) {
+                LAUNCHCHK(launch_welch_pipe(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, nullptr));
+                g.last_kernel = "k_welch_pipe";
             } else {
                 LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, partial,
                                        rp, allow_carry, nullptr, &g.last_kernel, segmean));

@@ -32,6 +32,21 @@ for hop in (2048, 1024, 4096):
         err = float(np.max(np.abs(p - ref) / (2e-4 * np.abs(ref) + 1e-6 * ref.max())))
         worst = max(worst, err)
         assert err <= 1.0, (hop, M, err)
+# plain accumulation (no detrend / a caller-supplied constant): the same pipeline without the one-pass epilogue
+for hop, M in ((2048, 333), (1024, 64), (4096, 7)):
+    n = (M - 1) * hop + nfft
+    s = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64) + np.complex64(0.3 + 0.1j)
+    p = E.welch_psd(s, win, hop, M, detrend=False, sided=E.SIDED_TWO, scale=1.0 / S2)
+    assert E.profile_last_kernel() == "k_welch_pipe", E.profile_last_kernel()
+    ref = O.welch_psd_stream(s, win, nfft, hop, M, 1.0, detrend_style=0)
+    err = float(np.max(np.abs(p - ref) / (2e-4 * np.abs(ref) + 1e-6 * ref.max())))
+    assert err <= 1.0, ("plain", hop, M, err)
+    mv = complex(0.25, 0.125)                                # exactly representable: the oracle subtracts it in complex64
+    p = E.welch_psd(s, win, hop, M, detrend=True, mean_value=mv, sided=E.SIDED_TWO, scale=1.0 / S2)
+    assert E.profile_last_kernel() == "k_welch_pipe", E.profile_last_kernel()
+    ref = O.welch_psd_stream((s - np.complex64(mv)).astype(np.complex64), win, nfft, hop, M, 1.0, detrend_style=0)
+    err = float(np.max(np.abs(p - ref) / (2e-4 * np.abs(ref) + 1e-6 * ref.max())))
+    assert err <= 1.0, ("const", hop, M, err)
 # the split ABI (shards: accumulate against the local estimate, finish with a mean handed in), real and complex input
 for cplx in (True, False):
     hop, M = 2048, 700
