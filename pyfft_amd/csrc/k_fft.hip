@@ -40,6 +40,8 @@ int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t n
 #define M_(XT)                                                                                        \
     if (ci.kind == 1) hipLaunchKernelGGL((k_fft_cols<XT::L, 1>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, \
                                          ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);                 \
+    else if (ci.kind == 3) hipLaunchKernelGGL((k_fft_cols<XT::L, 3>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, \
+                                              out, ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);       \
     else hipLaunchKernelGGL((k_fft_cols<XT::L, 0>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, ncb, nouter, \
                             es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);
     SP_DISPATCH_P(xf, M_)
@@ -55,12 +57,24 @@ int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B
     const int64_t total = A * B / fpw, cap = (int64_t)c.ncu * 4;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
 #define M_(XT)                                                                                        \
-    if (ro.co != nullptr) hipLaunchKernelGGL((k_fft_rows_rev<XT::L, true>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, \
-                                             in, out, A, B, conj_out, scale, xf.tb, ro);                               \
-    else hipLaunchKernelGGL((k_fft_rows_rev<XT::L, false>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
+    if (ro.co != nullptr && ro.kind == 2)                                                             \
+        hipLaunchKernelGGL((k_fft_rows_rev<XT::L, 2>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
+                           conj_out, scale, xf.tb, ro);                                               \
+    else if (ro.co != nullptr)                                                                        \
+        hipLaunchKernelGGL((k_fft_rows_rev<XT::L, 1>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
+                           conj_out, scale, xf.tb, ro);                                               \
+    else hipLaunchKernelGGL((k_fft_rows_rev<XT::L, 0>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
                             conj_out, scale, xf.tb, ro);
     SP_DISPATCH_P(xf, M_)
 #undef M_
+    return 0;
+}
+
+int launch_hilbert_mid(LaunchCtx c, cf *Z, int64_t M, BigTw bt) {
+    const int64_t n = M / 2 + 1;
+    const int64_t cap = (int64_t)c.ncu * 16;
+    const int64_t b = (n + 255) / 256;
+    hipLaunchKernelGGL(k_hilbert_mid, dim3((unsigned)(b < cap ? b : cap)), dim3(256), 0, c.stream, Z, M, bt);
     return 0;
 }
 

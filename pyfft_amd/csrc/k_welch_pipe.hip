@@ -23,6 +23,10 @@
 #ifndef SP_PIPE_SPREAD
 #define SP_PIPE_SPREAD 0
 #endif
+// SP_PIPE_NT=1: the front role streams the samples with the non-temporal policy
+#ifndef SP_PIPE_NT
+#define SP_PIPE_NT 1
+#endif
 #ifndef SP_PIPE_TIMING
 #define SP_PIPE_TIMING 0
 #endif
@@ -145,8 +149,17 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
                     dst[s] = raw[s] + mu;
                     continue;
                 }
+#if SP_PIPE_NT
+                if (CPLX) {
+                    const sp_f2v r = __builtin_nontemporal_load(reinterpret_cast<const sp_f2v *>(x) + ubase + off);
+                    dst[s] = mk(r.x, r.y);
+                } else {
+                    dst[s] = mk(__builtin_nontemporal_load(reinterpret_cast<const float *>(x) + ubase + off), 0.f);
+                }
+#else
                 if (CPLX) dst[s] = (reinterpret_cast<const cf *>(x) + ubase)[off];
                 else dst[s] = mk((reinterpret_cast<const float *>(x) + ubase)[off], 0.f);
+#endif
             }
         };
         auto issue = [&](cf (&dst)[SHIFT], int64_t q) __attribute__((always_inline)) { issue_part(dst, q, 0, SHIFT); };
@@ -293,6 +306,11 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
 #if SP_PIPE_TIMING
     if ((blockIdx.x == 3 || blockIdx.x == 200) && tid == 0)
         printf("block %d role %d: busy %llu wait %llu issue %llu cycles over %lld periods\n", (int)blockIdx.x, role, t_busy, t_wait, t_issue, (long long)periods);
+    if (blockIdx.x == 3 && (threadIdx.x & 63) == 0) {
+        // HW_ID (gfx9): wave_id [3:0], simd_id [5:4], pipe_id [7:6], cu_id [11:8], sh_id [12], se_id [15:13]
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+        printf("hwid wave %d role %d: simd %u wave_slot %u cu %u se %u\n", (int)(threadIdx.x >> 6), role, (hw >> 4) & 3, hw & 15, (hw >> 8) & 15, (hw >> 13) & 7);
+    }
 #endif
 #undef PIPE_SYNC
 }

@@ -313,8 +313,10 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restri
 // transform), so that the elementwise kernels in front of a long transform and their round trips through HBM disappear:
 //   kind 1: real samples, zero-padded: (r1[i] - m1, r2 ? r2[i] - m2 : 0) for i < nreal, else 0  (Hilbert's real -> complex
 //           pack; ccf's z = (x1 - m1) + i (x2 - m2): mom[0], mom[1] are the means; the zero half is not even loaded)
+//   kind 3: real samples taken in PAIRS, zero-padded: (r1[2i], r1[2i+1]) -- the half-length transform of a real signal
+//           (long Hilbert: z[n] = x[2n] + i x[2n+1], M = N/2 points)
 // (ccf's middle step, R[k] from Z[k] and Z[L-k], was tried as a third form: 388 VGPRs, 132 spilled at the 2-wave cap --
-//  it stays its own kernel, k_xc_mid)
+//  it stays its own kernel, k_xc_mid; so does the half-length Hilbert's, k_hilbert_mid)
 struct ColsIn {
     int kind;
     const float *r1, *r2;
@@ -352,6 +354,14 @@ __global__ __launch_bounds__(WgCfg<L>::WG, 2) void k_fft_cols(const cf *__restri
                 const float a = ci.r1[ic], b = ci.r2 ? ci.r2[ic] : m2;
                 v[t] = ok ? mk(a - m1, b - m2) : mk(0.f, 0.f);
             }
+        } else if constexpr (KIND == 3) {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t i = 2 * (base + (int64_t)(tid + C::T * t) * es);
+                const bool ok0 = i < ci.nreal, ok1 = i + 1 < ci.nreal;
+                const float a = ci.r1[ok0 ? i : 0], b = ci.r1[ok1 ? i + 1 : 0];
+                v[t] = mk(ok0 ? a : 0.f, ok1 ? b : 0.f);
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
@@ -385,12 +395,17 @@ __global__ __launch_bounds__(WgCfg<L>::WG, 2) void k_fft_cols(const cf *__restri
 // workgroup's outputs X[ka + A kb + A B kc] are contiguous
 // RowsOut (ccf): instead of the complex spectrum, write co[lag + n - 1] = mom[2] / Ltot * Re X[j] for the lags |lag| < n
 // (lag = j for j < n, j - Ltot for j > Ltot - n; see k_xc_out) -- the last elementwise kernel of the long ccf, fused
+// RowsOut kind 2 (half-length Hilbert, hilbert.py:54-67): the transform's output is z'[j] = y[2j] + i y[2j+1] with y the
+// Hilbert transform of the real signal rx; written is the analytic signal a[2j] = rx[2j] + i Re z'[j], a[2j+1] = rx[2j+1] +
+// i Im z'[j] (rx zero-padded beyond n samples) into co seen as complex -- two adjacent complex values per element
 struct RowsOut {
     float *co;
     int64_t n, Ltot;
     const double *mom;
+    const float *rx = nullptr;
+    int kind = 0;            // 0: plain spectrum, 1: ccf lags, 2: analytic signal from the half-length transform
 };
-template <int L, bool CCF>
+template <int L, int OKIND>
 __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restrict__ in, cf *__restrict__ out, int64_t A, int64_t B,
                                                                 int conj_out, float scale, XfTables tb, RowsOut ro) {
     using X = XfPow2<L>;
@@ -407,7 +422,16 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restr
         for (int t = 0; t < C::R; ++t) v[t] = row[tid + C::T * t];
         xf.fwd(v, lds, tid, L);
         const int64_t off = kb * A + ka;
-        if constexpr (CCF) {
+        if constexpr (OKIND == 2) {
+            float4 *ao = reinterpret_cast<float4 *>(ro.co);
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t j = (int64_t)(tid + C::T * t) * AB + off;
+                const bool ok0 = 2 * j < ro.n, ok1 = 2 * j + 1 < ro.n;
+                const float x0 = ro.rx[ok0 ? 2 * j : 0], x1 = ro.rx[ok1 ? 2 * j + 1 : 0];
+                ao[j] = make_float4(ok0 ? x0 : 0.f, scale * v[t].x, ok1 ? x1 : 0.f, so * scale * v[t].y);
+            }
+        } else if constexpr (OKIND == 1) {
             const float nrm = (float)(ro.mom[2] / (double)ro.Ltot);
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
@@ -1946,6 +1970,29 @@ static __global__ void k_xc_mid(const cf *__restrict__ Z, int64_t L, cf *__restr
         const cf z = Z[k], zm = Z[(L - k) & (L - 1)];
         const cf zz = cmul(z, zm);
         R[k] = mk(0.5f * zz.y, -0.25f * (cnorm(z) - cnorm(zm)));
+    }
+}
+// half-length Hilbert, middle step, in place: Z = FFT_M(x[2n] + i x[2n+1]) (M = N/2) -> Z'[k] = (conj(w)(Z[k] + conj Z[M-k]) -
+// w (Z[k] - conj Z[M-k]))/2, w = exp(-2 pi i k / N), Z'[0] = 0: the half-length spectrum of y = Im(analytic signal), i.e. the
+// real-FFT split, the analytic mask (hilbert.py:63-64: DC and Nyquist contribute to the real part only) and the inverse
+// real-FFT merge in one step.  A thread owns the pair (k, M-k).
+static __global__ void k_hilbert_mid(cf *__restrict__ Z, int64_t M, BigTw bt) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k <= M / 2; k += (int64_t)gridDim.x * blockDim.x) {
+        if (k == 0) {
+            Z[0] = mk(0.f, 0.f);
+            continue;
+        }
+        const int64_t km = M - k;
+        const cf a = Z[k], b = Z[km];
+        const cf w = cmul(bt.hi[k >> bt.lb], bt.lo[k & ((1 << bt.lb) - 1)]);          // W_N^k
+        const cf p = mk(a.x + b.x, a.y - b.y), q = mk(a.x - b.x, a.y + b.y);          // a + conj b, a - conj b
+        const cf r = cmul(cconj(w), p) - cmul(w, q);
+        Z[k] = mk(0.5f * r.x, 0.5f * r.y);
+        if (km != k) {
+            // for M-k: w' = -conj(w), p' = conj p, q' = -conj q  ->  conj(w') p' - w' q' = -w conj(p) - conj(w) conj(q)
+            const cf r2 = cmul(w, cconj(p)) + cmul(cconj(w), cconj(q));
+            Z[km] = mk(-0.5f * r2.x, -0.5f * r2.y);
+        }
     }
 }
 // co[j], j < 2n-1, 'full' order from r = real(FFT(conj R))/L:  lag >= 0 -> r[lag], lag < 0 -> r[L+lag]; times mom[2]

@@ -1555,7 +1555,31 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
         // long rows: pack -> FFT -> mask -> inverse FFT, each a multi-pass transform
         if (g.bigA.ensure(sizeof(cf) * (size_t)nfft)) return -1;
         cf *A = (cf *)g.bigA.p;
+        const int64_t Mh = nfft / 2;
+        const bool half_len = (nfft & (nfft - 1)) == 0 && big_three_pass(Mh) && !env_flag("SP_LONG_NOFUSE") &&
+                              !env_flag("SP_HILBERT_FULL");
+        BigTw btN;
+        if (half_len && get_bigtw(nfft, &btN)) return -1;
         for (int64_t b = 0; b < batch; ++b) {
+            if (half_len && (((uintptr_t)(od + b * nfft)) & 15) == 0) {
+                // real input: ONE half-length transform each way (z[n] = x[2n] + i x[2n+1], M = nfft/2 points).  Forward with
+                // the pair load fused into its first pass; k_hilbert_mid turns Z into the half-length spectrum of the
+                // Hilbert transform y (real-FFT split, analytic mask and inverse merge in one in-place step); the inverse
+                // transform's last pass writes a = x + i y.  960 MB of traffic at 2^24 points instead of 1.45 GB, on 64 MB
+                // buffers.
+                BigFuse fz;
+                fz.ci = ColsIn{3, xd + b * x_ld, nullptr, nullptr, nuse};
+                if (dev_fft_big_pow2(A, A, Mh, 0, 0, 1, &fz)) return -1;
+                LAUNCHCHK(launch_hilbert_mid(lc(), A, Mh, btN));
+                BigFuse fo;
+                fo.ro.co = reinterpret_cast<float *>(od + b * nfft);
+                fo.ro.n = nuse;
+                fo.ro.Ltot = nfft;
+                fo.ro.rx = xd + b * x_ld;
+                fo.ro.kind = 2;
+                if (dev_fft_big_pow2(A, A, Mh, 1, 0, 1, &fo)) return -1;
+                continue;
+            }
             if (big_three_pass(nfft) && !env_flag("SP_LONG_NOFUSE")) {
                 // real -> complex pack fused into the first pass of the forward transform (the zero padding is not loaded),
                 // the analytic-signal mask into the first pass of the inverse one

@@ -531,6 +531,24 @@ def test_hilbert_long_rows(E):
     assert np.max(np.abs(z[0] - O.hilbert(u[0], nfft=1 << 16))) <= 1e-4 * np.abs(u).max()
 
 
+def test_hilbert_long_half_length(E):
+    """power-of-two lengths from 2^21: the real input goes through ONE half-length transform each way (pair load fused
+    into the first pass, k_hilbert_mid, analytic signal written by the last pass); full, zero-padded (odd sample count)
+    and truncated rows, two rows with an odd row pitch"""
+    rng = np.random.default_rng(32)
+    n = 1 << 21
+    u = rng.standard_normal((2, n + 5))[:, : n + 5]
+    for nuse in (n, 1500001, n + 5):
+        z = E.hilbert_rows(np.ascontiguousarray(u[:, :nuse]), n)
+        ref = O.hilbert(u[:, :nuse], nfft=n)
+        assert z.shape == (2, n)
+        assert np.max(np.abs(z - ref)) <= 2e-5 * np.abs(ref).max(), nuse
+    u = rng.standard_normal(1 << 22) + 3.0                      # a mean: DC stays in the real part only
+    z = E.hilbert_rows(u[None, :], 1 << 22)[0]
+    ref = O.hilbert(u)
+    assert np.max(np.abs(z - ref)) <= 2e-5 * np.abs(ref).max()
+
+
 # ---------------------------------------------------------------- A11 ccf
 def test_xcorr_golden(E):
     g = load_golden("ccf")
