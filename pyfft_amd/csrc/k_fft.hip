@@ -60,6 +60,9 @@ int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B
     if (ro.co != nullptr && ro.kind == 2)                                                             \
         hipLaunchKernelGGL((k_fft_rows_rev<XT::L, 2>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
                            conj_out, scale, xf.tb, ro);                                               \
+    else if (ro.co != nullptr && ro.kind == 3)                                                        \
+        hipLaunchKernelGGL((k_fft_rows_rev<XT::L, 3>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
+                           conj_out, scale, xf.tb, ro);                                               \
     else if (ro.co != nullptr)                                                                        \
         hipLaunchKernelGGL((k_fft_rows_rev<XT::L, 1>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, A, B, \
                            conj_out, scale, xf.tb, ro);                                               \
@@ -229,6 +232,11 @@ int launch_spec_mul(LaunchCtx c, cf *X, const cf *H, int64_t n) {
 }
 int launch_xc_pack(LaunchCtx c, const float *x1, const float *x2, int64_t n, int64_t L, const double *mom, cf *z) {
     hipLaunchKernelGGL(k_xc_pack, dim3(ew_blocks(L, c.ncu)), dim3(256), 0, c.stream, x1, x2, n, L, mom, z);
+    return 0;
+}
+int launch_xc_mid_half(LaunchCtx c, const cf *Z, int64_t L, BigTw bt, cf *Zp) {
+    const int64_t b = (L / 2 + 255) / 256, cap = (int64_t)c.ncu * 16;
+    hipLaunchKernelGGL(k_xc_mid_half, dim3((unsigned)(b < cap ? b : cap)), dim3(256), 0, c.stream, Z, L, bt, Zp);
     return 0;
 }
 int launch_xc_mid(LaunchCtx c, const cf *Z, int64_t L, cf *R) {

@@ -403,7 +403,8 @@ struct RowsOut {
     int64_t n, Ltot;
     const double *mom;
     const float *rx = nullptr;
-    int kind = 0;            // 0: plain spectrum, 1: ccf lags, 2: analytic signal from the half-length transform
+    int kind = 0;            // 0: plain spectrum, 1: ccf lags, 2: analytic signal from the half-length transform,
+                             // 3: ccf lags from the half-length inverse (two lags per element)
 };
 template <int L, int OKIND>
 __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restrict__ in, cf *__restrict__ out, int64_t A, int64_t B,
@@ -430,6 +431,20 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restr
                 const bool ok0 = 2 * j < ro.n, ok1 = 2 * j + 1 < ro.n;
                 const float x0 = ro.rx[ok0 ? 2 * j : 0], x1 = ro.rx[ok1 ? 2 * j + 1 : 0];
                 ao[j] = make_float4(ok0 ? x0 : 0.f, scale * v[t].x, ok1 ? x1 : 0.f, so * scale * v[t].y);
+            }
+        } else if constexpr (OKIND == 3) {
+            // ccf, half-length inverse: element j holds M (r[2j] - i r[2j+1]); Ltot = 2M is the padded correlation length
+            const float nrm = (float)(2.0 * ro.mom[2] / (double)ro.Ltot);
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t j2 = 2 * ((int64_t)(tid + C::T * t) * AB + off);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int64_t idx = j2 + e;
+                    const float val = nrm * (e ? -v[t].y : v[t].x);
+                    if (idx < ro.n) ro.co[idx + ro.n - 1] = val;
+                    else if (idx > ro.Ltot - ro.n) ro.co[idx - ro.Ltot + ro.n - 1] = val;
+                }
             }
         } else if constexpr (OKIND == 1) {
             const float nrm = (float)(ro.mom[2] / (double)ro.Ltot);
@@ -1970,6 +1985,22 @@ static __global__ void k_xc_mid(const cf *__restrict__ Z, int64_t L, cf *__restr
         const cf z = Z[k], zm = Z[(L - k) & (L - 1)];
         const cf zz = cmul(z, zm);
         R[k] = mk(0.5f * zz.y, -0.25f * (cnorm(z) - cnorm(zm)));
+    }
+}
+// ccf with a half-length inverse (the correlation is real): from Z = FFT_L(a + i b), R(k) = A conj(B) as in k_xc_mid, and
+// Z'[k] = ((R(k) + conj R(M-k)) + i conj(w) (R(k) - conj R(M-k)))/2, M = L/2, w = exp(-2 pi i k / L): the M-point spectrum of
+// z'[n] = r[2n] + i r[2n+1].  Stored CONJUGATED (the inverse runs as a forward transform of the conjugate).
+static __global__ void k_xc_mid_half(const cf *__restrict__ Z, int64_t L, BigTw bt, cf *__restrict__ Zp) {
+    const int64_t M = L / 2;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < M; k += (int64_t)gridDim.x * blockDim.x) {
+        const cf a = Z[k], am = Z[(L - k) & (L - 1)], b = Z[M - k], bm = Z[M + k];
+        const cf za = cmul(a, am), zb = cmul(b, bm);
+        const cf rk = mk(0.5f * za.y, 0.25f * (cnorm(a) - cnorm(am)));
+        const cf rmc = mk(0.5f * zb.y, -0.25f * (cnorm(b) - cnorm(bm)));              // conj R(M-k)
+        const cf w = cmul(bt.hi[k >> bt.lb], bt.lo[k & ((1 << bt.lb) - 1)]);          // W_L^k
+        const cf s = rk + rmc, d = rk - rmc;
+        const cf t = cmul(cconj(w), d);                                               // i t = (-t.y, t.x)
+        Zp[k] = mk(0.5f * (s.x - t.y), -0.5f * (s.y + t.x));
     }
 }
 // half-length Hilbert, middle step, in place: Z = FFT_M(x[2n] + i x[2n+1]) (M = N/2) -> Z'[k] = (conj(w)(Z[k] + conj Z[M-k]) -

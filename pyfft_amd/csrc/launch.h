@@ -116,6 +116,7 @@ int launch_blue_post(LaunchCtx c, const cf *in, const cf *chirp, int64_t n, int 
 int launch_hilbert_mask(LaunchCtx c, cf *X, int64_t n);
 int launch_xc_pack(LaunchCtx c, const float *x1, const float *x2, int64_t n, int64_t L, const double *mom, cf *z);
 int launch_xc_mid(LaunchCtx c, const cf *Z, int64_t L, cf *R);
+int launch_xc_mid_half(LaunchCtx c, const cf *Z, int64_t L, BigTw bt, cf *Zp);
 int launch_xc_out(LaunchCtx c, const cf *r, int64_t n, int64_t L, const double *mom, float *co);
 bool welch_carry_eligible(const Xf &xf, int hop, bool lin);
 int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, const float *trend,

@@ -563,10 +563,11 @@ def test_xcorr_golden(E):
     assert abs(a[n - 1] - 1.0) < 1e-5 and np.max(np.abs(a - a[::-1])) < 1e-5
 
 
-@pytest.mark.parametrize("n", [5000, 70001, 1 << 18])
+@pytest.mark.parametrize("n", [5000, 70001, 1 << 18, 300001, 600001, 1100003])
 def test_xcorr_long(E, n):
     """more lags than one workgroup holds: the reference's O(N^2) np.correlate is infeasible here; the oracle's
-    FFT formulation (asserted equal to the direct form on the CPU) is the checker"""
+    FFT formulation (asserted equal to the direct form on the CPU) is the checker.  300001: three-pass transforms of 2^20
+    points; 600001 and 1100003: the inverse at half length (2^20 and 2^21 points for 2^21 and 2^22 lags)"""
     rng = np.random.default_rng(n % 1000)
     k = np.arange(n)
     x1 = np.sin(0.01 * k) + rng.standard_normal(n) + 1.5
