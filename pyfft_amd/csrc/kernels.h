@@ -317,6 +317,9 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restri
 //           (long Hilbert: z[n] = x[2n] + i x[2n+1], M = N/2 points)
 // (ccf's middle step, R[k] from Z[k] and Z[L-k], was tried as a third form: 388 VGPRs, 132 spilled at the 2-wave cap --
 //  it stays its own kernel, k_xc_mid; so does the half-length Hilbert's, k_hilbert_mid)
+#ifndef SP_BIGTW_REC
+#define SP_BIGTW_REC 1
+#endif
 struct ColsIn {
     int kind;
     const float *r1, *r2;
@@ -355,12 +358,25 @@ __global__ __launch_bounds__(WgCfg<L>::WG, 2) void k_fft_cols(const cf *__restri
                 v[t] = ok ? mk(a - m1, b - m2) : mk(0.f, 0.f);
             }
         } else if constexpr (KIND == 3) {
+            if (ci.r2 != nullptr) {
+                // r2 == r1 flags an 8-byte aligned row: one 8-byte load per pair (the scalar form below ran this pass at
+                // 1.5 TB/s against 2.7 for the plain complex load)
 #pragma unroll
-            for (int t = 0; t < C::R; ++t) {
-                const int64_t i = 2 * (base + (int64_t)(tid + C::T * t) * es);
-                const bool ok0 = i < ci.nreal, ok1 = i + 1 < ci.nreal;
-                const float a = ci.r1[ok0 ? i : 0], b = ci.r1[ok1 ? i + 1 : 0];
-                v[t] = mk(ok0 ? a : 0.f, ok1 ? b : 0.f);
+                for (int t = 0; t < C::R; ++t) {
+                    const int64_t i = 2 * (base + (int64_t)(tid + C::T * t) * es);
+                    const bool ok0 = i < ci.nreal, ok1 = i + 1 < ci.nreal;
+                    const cf pr = *reinterpret_cast<const cf *>(ci.r1 + (ok1 ? i : 0));
+                    const float a0 = ok1 ? pr.x : (ok0 ? ci.r1[i] : 0.f);
+                    v[t] = mk(a0, ok1 ? pr.y : 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < C::R; ++t) {
+                    const int64_t i = 2 * (base + (int64_t)(tid + C::T * t) * es);
+                    const bool ok0 = i < ci.nreal, ok1 = i + 1 < ci.nreal;
+                    const float a = ci.r1[ok0 ? i : 0], b = ci.r1[ok1 ? i + 1 : 0];
+                    v[t] = mk(ok0 ? a : 0.f, ok1 ? b : 0.f);
+                }
             }
         } else {
 #pragma unroll
@@ -381,10 +397,30 @@ __global__ __launch_bounds__(WgCfg<L>::WG, 2) void k_fft_cols(const cf *__restri
         for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, si * v[t].y);
         xf.fwd(v, lds, tid, L);
         const int64_t mc = twmul * col;
+#if SP_BIGTW_REC
+        if constexpr (C::R == 16) {
+            // W^{mc (tid + T t)} = W^{mc tid} (W^{mc T})^t: two table look-ups per thread instead of sixteen (each look-up is
+            // two 8-byte loads whose addresses differ in every lane -- 32 scattered loads per thread and block), the powers of
+            // the step by squaring (s, s^2, s^4, s^8) and at most three more products: every factor is <= 7 complex
+            // multiplications away from a table entry (phase error <= 5e-7)
+            auto look = [&](int64_t m) __attribute__((always_inline)) { return cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]); };
+            const cf w0 = look(mc * (int64_t)tid), s1 = look(mc * (int64_t)C::T);
+            const cf s2 = cmul(s1, s1), s4 = cmul(s2, s2), s8 = cmul(s4, s4);
+            const cf q3 = cmul(s2, s1), q5 = cmul(s4, s1), q6 = cmul(s4, s2), q9 = cmul(s8, s1), q10 = cmul(s8, s2), q12 = cmul(s8, s4);
+            const cf q7 = cmul(q6, s1), q11 = cmul(q10, s1), q13 = cmul(q12, s1), q14 = cmul(q12, s2);
+            const cf q15 = cmul(q14, s1);
+            const cf q[16] = {mk(1.f, 0.f), s1, s2, q3, s4, q5, q6, q7, s8, q9, q10, q11, q12, q13, q14, q15};
+            v[0] = cmul(v[0], w0);
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) {
-            const int64_t m = mc * (int64_t)(tid + C::T * t);
-            v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
+            for (int t = 1; t < 16; ++t) v[t] = cmul(v[t], cmul(w0, q[t]));
+        } else
+#endif
+        {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t m = mc * (int64_t)(tid + C::T * t);
+                v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
+            }
         }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) out[base + (int64_t)(tid + C::T * t) * es] = v[t];

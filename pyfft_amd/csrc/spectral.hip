@@ -1568,7 +1568,8 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
                 // transform's last pass writes a = x + i y.  960 MB of traffic at 2^24 points instead of 1.45 GB, on 64 MB
                 // buffers.
                 BigFuse fz;
-                fz.ci = ColsIn{3, xd + b * x_ld, nullptr, nullptr, nuse};
+                const float *row = xd + b * x_ld;
+                fz.ci = ColsIn{3, row, (((uintptr_t)row) & 7) == 0 ? row : nullptr, nullptr, nuse};      // r2 == r1: aligned pairs
                 if (dev_fft_big_pow2(A, A, Mh, 0, 0, 1, &fz)) return -1;
                 LAUNCHCHK(launch_hilbert_mid(lc(), A, Mh, btN));
                 BigFuse fo;
