@@ -223,6 +223,25 @@ struct BigTw {
     int64_t mod;       // > 0: rows are numbered modulo `mod` (a batch of independent long transforms in one launch)
 };
 
+#ifndef SP_BIGTW_REC
+#define SP_BIGTW_REC 1
+#endif
+// v[t] *= W^{e0 + es t}, t = 0..15, from TWO table look-ups (W^{e0}, W^{es}): the powers of the step by squaring (s, s^2,
+// s^4, s^8) and at most three more products, so every factor is <= 7 complex multiplications away from a table entry
+// (phase error <= 5e-7).  The direct form is 16 look-ups of two 8-byte loads each whose addresses differ in every lane.
+__device__ __forceinline__ void bigtw_apply16(cf (&v)[16], const BigTw &bt, int64_t e0, int64_t es) {
+    auto look = [&](int64_t m) __attribute__((always_inline)) { return cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]); };
+    const cf w0 = look(e0), s1 = look(es);
+    const cf s2 = cmul(s1, s1), s4 = cmul(s2, s2), s8 = cmul(s4, s4);
+    const cf q3 = cmul(s2, s1), q5 = cmul(s4, s1), q6 = cmul(s4, s2), q9 = cmul(s8, s1), q10 = cmul(s8, s2), q12 = cmul(s8, s4);
+    const cf q7 = cmul(q6, s1), q11 = cmul(q10, s1), q13 = cmul(q12, s1), q14 = cmul(q12, s2);
+    const cf q15 = cmul(q14, s1);
+    const cf q[16] = {mk(1.f, 0.f), s1, s2, q3, s4, q5, q6, q7, s8, q9, q10, q11, q12, q13, q14, q15};
+    v[0] = cmul(v[0], w0);
+#pragma unroll
+    for (int t = 1; t < 16; ++t) v[t] = cmul(v[t], cmul(w0, q[t]));
+}
+
 template <class X>
 __global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in, cf *__restrict__ out, int64_t batch,
                                                        int inverse, XfTables tb, BigTw bt) {
@@ -244,10 +263,18 @@ __global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in,
         for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, sgn * v[t].y);
         xf.fwd(v, lds, tid, n);
         if (bt.lo != nullptr) {
+            const int64_t rowm = bt.mod > 0 ? bl % bt.mod : bl;
+#if SP_BIGTW_REC
+            if constexpr (C::R == 16) {
+                bigtw_apply16(v, bt, rowm * (int64_t)tid, rowm * (int64_t)C::T);
+            } else
+#endif
+            {
 #pragma unroll
-            for (int t = 0; t < C::R; ++t) {
-                const int64_t m = (bt.mod > 0 ? bl % bt.mod : bl) * (int64_t)(tid + C::T * t);
-                v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
+                for (int t = 0; t < C::R; ++t) {
+                    const int64_t m = rowm * (int64_t)(tid + C::T * t);
+                    v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
+                }
             }
         }
         if (act) {
@@ -317,9 +344,6 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restri
 //           (long Hilbert: z[n] = x[2n] + i x[2n+1], M = N/2 points)
 // (ccf's middle step, R[k] from Z[k] and Z[L-k], was tried as a third form: 388 VGPRs, 132 spilled at the 2-wave cap --
 //  it stays its own kernel, k_xc_mid; so does the half-length Hilbert's, k_hilbert_mid)
-#ifndef SP_BIGTW_REC
-#define SP_BIGTW_REC 1
-#endif
 struct ColsIn {
     int kind;
     const float *r1, *r2;
@@ -403,16 +427,7 @@ __global__ __launch_bounds__(WgCfg<L>::WG, 2) void k_fft_cols(const cf *__restri
             // two 8-byte loads whose addresses differ in every lane -- 32 scattered loads per thread and block), the powers of
             // the step by squaring (s, s^2, s^4, s^8) and at most three more products: every factor is <= 7 complex
             // multiplications away from a table entry (phase error <= 5e-7)
-            auto look = [&](int64_t m) __attribute__((always_inline)) { return cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]); };
-            const cf w0 = look(mc * (int64_t)tid), s1 = look(mc * (int64_t)C::T);
-            const cf s2 = cmul(s1, s1), s4 = cmul(s2, s2), s8 = cmul(s4, s4);
-            const cf q3 = cmul(s2, s1), q5 = cmul(s4, s1), q6 = cmul(s4, s2), q9 = cmul(s8, s1), q10 = cmul(s8, s2), q12 = cmul(s8, s4);
-            const cf q7 = cmul(q6, s1), q11 = cmul(q10, s1), q13 = cmul(q12, s1), q14 = cmul(q12, s2);
-            const cf q15 = cmul(q14, s1);
-            const cf q[16] = {mk(1.f, 0.f), s1, s2, q3, s4, q5, q6, q7, s8, q9, q10, q11, q12, q13, q14, q15};
-            v[0] = cmul(v[0], w0);
-#pragma unroll
-            for (int t = 1; t < 16; ++t) v[t] = cmul(v[t], cmul(w0, q[t]));
+            bigtw_apply16(v, bt, mc * (int64_t)tid, mc * (int64_t)C::T);
         } else
 #endif
         {
