@@ -40,11 +40,12 @@
 namespace sp {
 
 #if !SP_PACKED
-template <bool CPLX, int SHIFT, bool ONEPASS>
+template <bool CPLX, int SHIFT, int MODE>      // MODE 0: plain accumulation, 1: one-pass mean detrend, 2: moments per frame (cog)
 __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, const float *__restrict__ win,
                                                      int64_t nframes, int64_t fpg, float *__restrict__ trend, XfTables tb,
                                                      float *__restrict__ partial, cf *__restrict__ spartial) {
     constexpr int N = 4096;
+    constexpr bool ONEPASS = MODE == 1, COG = MODE == 2;
     using PL = FftPlan<N>;
     using F = WgFft<N>;
     constexpr int T = PL::T, R = PL::R, KEEP = R - SHIFT, IMG = PL::LDS_ELEMS;
@@ -281,6 +282,16 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
 #pragma unroll
         for (int t = 0; t < R; ++t) acc[t] = 0.f;
         cf va[R], vb[R];
+        // COG (Doppler.cog / cogspec, Doppler.py:43-81): instead of summing |X|^2 over the frames, every frame's moments
+        // sum ks |X|^2, sum |X|^2 (signed bin index ks, every bin) are reduced across the wave; a wave keeps the moments of its
+        // last 64 frames spread over its lanes and writes them with one coalesced store, layout slots[wave][frame] (as
+        // k_welch_carry_cog; k_cog_finish adds the four waves of a frame)
+        cf pend = mk(0.f, 0.f);
+        auto flush = [&](int64_t i) __attribute__((always_inline)) {
+            const int sel = (int)(i & 63), li = tid & 63;
+            const int64_t gg = g0 + (i - sel) + li;
+            if (li <= sel && gg < nframes) reinterpret_cast<cf *>(partial)[(int64_t)(tid >> 6) * nframes + gg] = pend;
+        };
         auto step = [&](cf (&fill)[R], cf (&use)[R], int64_t p, const cf *src) __attribute__((always_inline)) {
             if (p >= 3 && p <= trips + 2) {
                 if constexpr (!(SP_ABLATE & 2)) f.template gather<1>(fill, src, tid);
@@ -291,8 +302,25 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
             }
             if (p >= 4 && p <= trips + 3) {
                 f.template bfly<2>(use, tid);
+                if constexpr (COG) {
+                    // ks = tid + c_t with c_t = T t - (N in the upper half): sum ks p = tid sum p + sum c_t p
+                    float numc = 0.f, den = 0.f;
 #pragma unroll
-                for (int t = 0; t < R; ++t) acc[t] = fmaf(use[t].y, use[t].y, fmaf(use[t].x, use[t].x, acc[t]));
+                    for (int t = 0; t < R; ++t) {
+                        const float pw = cnorm(use[t]);
+                        numc = fmaf(pw, (float)(T * t - (t >= R / 2 ? N : 0)), numc);
+                        den += pw;
+                    }
+                    float num = fmaf((float)tid, den, numc);
+                    num = wave_sum64(num);
+                    den = wave_sum64(den);
+                    const int64_t i = p - 4;
+                    if ((tid & 63) == (int)(i & 63)) pend = mk(num, den);
+                    if ((i & 63) == 63 || i == trips - 1) flush(i);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < R; ++t) acc[t] = fmaf(use[t].y, use[t].y, fmaf(use[t].x, use[t].x, acc[t]));
+                }
             }
             PIPE_SYNC();
         };
@@ -300,8 +328,10 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
             step(va, vb, p, imgB + IMG);
             if (p + 1 < periods) step(vb, va, p + 1, imgB);
         }
+        if constexpr (!COG) {
 #pragma unroll
-        for (int t = 0; t < R; ++t) partial[gid * N + tid + T * t] = acc[t];
+            for (int t = 0; t < R; ++t) partial[gid * N + tid + T * t] = acc[t];
+        }
     }
 #if SP_PIPE_TIMING
     if ((blockIdx.x == 3 || blockIdx.x == 200) && tid == 0)
@@ -326,8 +356,9 @@ bool welch_pipe_eligible(const Xf &xf, int hop) {
 #endif
 }
 
+// mode 2: `partial` is the cog slot array [4][nframes] of (num, den) pairs (spartial unused)
 int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, float *trend,
-                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial) {
+                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial, int mode) {
 #if SP_PACKED
     return -1;
 #else
@@ -346,10 +377,12 @@ int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, i
     const int shift = hop / 256;
 #define PIPE_S_(CP, OP)                                                                               \
     if (shift == 8) PIPE_(CP, 8, OP) else if (shift == 4) PIPE_(CP, 4, OP) else PIPE_(CP, 16, OP)
-    if (spartial) {
-        if (cplx) { PIPE_S_(true, true) } else { PIPE_S_(false, true) }
+    if (mode == 2) {
+        if (cplx) { PIPE_S_(true, 2) } else { PIPE_S_(false, 2) }
+    } else if (spartial) {
+        if (cplx) { PIPE_S_(true, 1) } else { PIPE_S_(false, 1) }
     } else {
-        if (cplx) { PIPE_S_(true, false) } else { PIPE_S_(false, false) }
+        if (cplx) { PIPE_S_(true, 0) } else { PIPE_S_(false, 0) }
     }
 #undef PIPE_S_
 #undef PIPE_

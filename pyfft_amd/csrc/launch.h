@@ -124,7 +124,7 @@ int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int ho
                  const char **kname, int segmean = 0);
 bool welch_pipe_eligible(const Xf &xf, int hop);
 int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, float *trend,
-                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial);
+                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial, int mode = 0);
 int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, double *part, float *trend);
 int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *partial, const cf *spartial,
                      int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st, double *sum_out);

@@ -1513,11 +1513,16 @@ int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int 
             LAUNCHCHK(launch_long_cog(lc(), S, m, nfft, klo, khi, acc, f0));
         }
     } else {
-        const RunPart rp = run_partition(xf.L, nframes, g.ncu);
+        const bool full_band = klo <= 0 && khi >= nfft / 2;
+        const bool pipe = !segmean && detrend != 2 && full_band && !env_flag("SP_COG_GENERIC") && welch_pipe_wanted(xf, hop, nframes);
+        const RunPart rp = pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc()) : run_partition(xf.L, nframes, g.ncu);
         // streaming form (every sample read once, the overlap carried in registers) when the shape allows; SP_COG_GENERIC=1
-        // forces the generic frame kernel (A/B test)
+        // forces the generic frame kernel (A/B test); nfft 4096: the pipeline of specialised waves (k_welch_pipe.hip, mode 2)
         int generic = 1;
-        if (!segmean && detrend != 2 && !env_flag("SP_COG_GENERIC"))
+        if (pipe) {
+            LAUNCHCHK(launch_welch_pipe(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, (float *)acc, rp, nullptr, 2));
+            generic = 0;
+        } else if (!segmean && detrend != 2 && !env_flag("SP_COG_GENERIC"))
             generic = launch_cog_carry(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, acc, rp, klo, khi);
         if (generic < 0) return fail("sp_stft_cog: launch failed");
         if (generic)

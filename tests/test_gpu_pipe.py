@@ -47,6 +47,17 @@ for hop, M in ((2048, 333), (1024, 64), (4096, 7)):
     ref = O.welch_psd_stream((s - np.complex64(mv)).astype(np.complex64), win, nfft, hop, M, 1.0, detrend_style=0)
     err = float(np.max(np.abs(p - ref) / (2e-4 * np.abs(ref) + 1e-6 * ref.max())))
     assert err <= 1.0, ("const", hop, M, err)
+# centre of gravity per frame (Doppler.cog / cogspec): the back role reduces each frame's moments instead of summing |X|^2
+fs = 1.0e3
+for hop, M in ((2048, 200), (1024, 131), (4096, 65)):
+    n = (M - 1) * hop + nfft
+    tt = np.arange(n) / fs
+    f_inst = 120.0 * np.sin(2 * np.pi * tt / (n / fs))
+    s = (np.exp(2j * np.pi * np.cumsum(f_inst) / fs) + 0.1 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    c = E.stft_cog(s, np.ones(nfft), hop, M, fs)
+    _, ref = O.cog_frames(tt, s, fs, win=nfft, ov=1.0 - hop / nfft)
+    assert c.shape == ref.shape
+    assert np.max(np.abs(c - ref)) <= 2e-4 * fs, ("cog", hop, M, float(np.max(np.abs(c - ref))))
 # the split ABI (shards: accumulate against the local estimate, finish with a mean handed in), real and complex input
 for cplx in (True, False):
     hop, M = 2048, 700
