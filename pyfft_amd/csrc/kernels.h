@@ -1817,8 +1817,11 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
 #pragma unroll
     for (int t = 0; t < C::R; ++t) w[t] = win[tid + C::T * t];
     x += (int64_t)blockIdx.y * x_cs;
-    if (out_power) out = reinterpret_cast<float *>(out) + (int64_t)blockIdx.y * out_cs;
-    else out = reinterpret_cast<cf *>(out) + (int64_t)blockIdx.y * out_cs;
+    // out_power 0: complex rows [frame][bin]; 1: float power; 2: complex, the two frames of a pair side by side and the
+    // (<= 64) channels interleaved per group of 8 bins, [pair][bin group][channel][8][2] (one 16-byte store per bin; the layout
+    // the bf16 contraction of cfg5 reads, k_csdm_bf16.hip; the channel is blockIdx.y, out_cs unused, out_ld a multiple of 8)
+    if (out_power == 1) out = reinterpret_cast<float *>(out) + (int64_t)blockIdx.y * out_cs;
+    else if (out_power != 2) out = reinterpret_cast<cf *>(out) + (int64_t)blockIdx.y * out_cs;
     const Trend tr = load_trend(trend + 4 * blockIdx.y);
     const int nb = out_ld > 0 ? out_ld : nbins_of(n, sided);
     const int64_t npairs = (nframes + 1) / 2;
@@ -1879,7 +1882,14 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
                 const cf z = v[t];
                 const cf xa = mk(0.5f * (z.x + zm.x), 0.5f * (z.y - zm.y));          // (Z + conj Zm)/2
                 const cf xb = mk(0.5f * (z.y + zm.y), -0.5f * (z.x - zm.x));         // (Z - conj Zm)/(2i)
-                if (out_power) {
+                if (out_power == 2) {
+                    const float a = bin_doubled(k, N, sided) ? amp * 1.41421356237309504880f : amp;
+                    const float hb = has_b ? a : 0.f;
+                    // [pair][bin group of 8][channel slot of 64][bin in group][frame of the pair]: for one (pair, group) the
+                    // 64 channels' 128-byte lines are 8 KiB contiguous -- what one tile row of k_csdm_bf16 streams
+                    reinterpret_cast<float4 *>(out)[((((ga / 2) * (int64_t)(nb / 8) + slot / 8) * 64 + blockIdx.y) * 8) + (slot & 7)] =
+                        make_float4(a * xa.x, a * xa.y, hb * xb.x, hb * xb.y);
+                } else if (out_power) {
                     reinterpret_cast<float *>(out)[ga * nb + slot] = amp * cnorm(xa);
                     if (has_b) reinterpret_cast<float *>(out)[(ga + 1) * nb + slot] = amp * cnorm(xb);
                 } else {

@@ -1296,8 +1296,12 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     // bins).  With the natural pitch nb = nfft/2 + 1 (odd) almost every 16-bin tile row straddled two lines and the
     // contraction fetched 1.9x its algorithmic bytes (calibrated PMC: profiles/r02_fetch_size_calibration.txt)
     const bool rp_stft = !lng && !xf.blue && xf.L >= 32 && nch <= 65535;
-    const int ld = (use_fused && (rp_stft || lng) && !env_flag("SP_CSDM_NOPAD")) ? (nb + 15) / 16 * 16 : nb;
-    const size_t sbytes = sizeof(cf) * (size_t)nch * (size_t)mc * (size_t)ld;
+    // bf16-split contraction (k_csdm_bf16.hip): needs the pair-interleaved spectra the real-pair STFT kernel can write
+    const bool use_bf16 = use_fused && rp_stft && !env_flag("SP_CSDM_FP32");
+    const int ld = use_bf16 ? (nb + 7) / 8 * 8
+                            : ((use_fused && (rp_stft || lng) && !env_flag("SP_CSDM_NOPAD")) ? (nb + 15) / 16 * 16 : nb);
+    const size_t sbytes = use_bf16 ? sizeof(cf) * 2 * (size_t)64 * (size_t)((mc + 1) / 2) * (size_t)ld       // 64 channel slots
+                                   : sizeof(cf) * (size_t)nch * (size_t)mc * (size_t)ld;
     const size_t tbytes = use_fused ? sizeof(cf) * (size_t)nchp * (size_t)mcp * 16
                                     : (use_mfma ? sizeof(cf) * (size_t)nchp * (size_t)mcp * (size_t)nb : sbytes);
     if (g.cmS.ensure(sbytes) || g.cmT.ensure(tbytes)) return -1;
@@ -1316,6 +1320,11 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                     return -1;
                 LAUNCHCHK(launch_long_stft_out(lc(), S, m, nfft, SP_SIDED_HALF, 1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)ld, 0, ld));
             }
+        } else if (use_bf16) {
+            const RunPart rp = run_partition_2d(xf.L, (m + 1) / 2, g.ncu, nch);
+            LAUNCHCHK(launch_stft_rp(lc(), xd + (size_t)f0 * (size_t)hop, (const float *)win_d, hop, m, tb.f + 4 * nch,
+                                     detrend == 2, xf, rp, SP_SIDED_HALF, 1.f, 2, Xs, nullptr, nch, x_ld,
+                                     ((m + 1) / 2) * (int64_t)ld * 2, ld));
         } else if (rp_stft && (m >= 2 || ld != nb)) {
             // all channels in one grid, two real frames per transform
             // (channels x groups) workgroups: about 8 per CU in all, so that each amortises its twiddle prologue over a long
@@ -1332,7 +1341,9 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                                       (const float *)win_d, hop, m, tb.f + 4 * (nch + c), detrend == 2, xf, rp, SP_SIDED_HALF,
                                       1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
         }
-        if (use_fused) {
+        if (use_bf16) {
+            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, m, nb, G, ld));
+        } else if (use_fused) {
             LAUNCHCHK(launch_csdm_fused(lc(), Xs, Xt, nch, m, nb, G, ld));
         } else if (use_mfma) {
             const int64_t mp = (m + 31) / 32 * 32;
