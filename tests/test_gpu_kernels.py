@@ -435,6 +435,33 @@ def test_csd_matrix(E, nch, nfft, hop, nsig):
     np.testing.assert_allclose(G[:, 0, 0].real, p0, rtol=1e-4, atol=1e-6 * p0.max())
 
 
+@pytest.mark.parametrize("nch,nfft,hop,nsig", [(64, 4096, 2048, 4096 + 2048 * 300), (37, 512, 256, 512 + 256 * 1001),
+                                                (64, 1024, 256, 1024 + 256 * 77)])
+def test_csd_matrix_bf16_split_is_float32_accurate(E, nch, nfft, hop, nsig):
+    """the contraction on the bf16 matrix cores (k_csdm_bf16: x = h + m + l, six piece products) against the float32-MFMA
+    form (SP_CSDM_FP32=1) and the float64 oracle: the split must not cost accuracy.  Odd frame counts (a half-filled last
+    pair), fewer than 64 channels (masked channel slots) and few bin groups (frame-pair slices added atomically)"""
+    import os
+    rng = np.random.default_rng(nch + nfft)
+    k = np.arange(nsig)
+    common = np.sin(0.11 * k) + rng.standard_normal(nsig)
+    x = np.stack([(0.5 + 0.03 * c) * np.roll(common, c % 5) + 0.3 * rng.standard_normal(nsig) + 0.2 * c
+                  for c in range(nch)]).astype(np.float32)
+    M = (nsig - nfft) // hop + 1
+    win = O.windows("Hanning", nwins=nfft)
+    G = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+    os.environ["SP_CSDM_FP32"] = "1"
+    try:
+        G32 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+    finally:
+        del os.environ["SP_CSDM_FP32"]
+    ref = O.csd_matrix(x.astype(np.float64), win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+    peak = np.abs(ref).max()
+    e16, e32 = np.max(np.abs(G - ref)) / peak, np.max(np.abs(G32 - ref)) / peak
+    assert e16 <= 2e-5 and e16 <= 3.0 * e32 + 1e-6, (e16, e32)
+    assert np.max(np.abs(G - np.conj(np.swapaxes(G, 1, 2)))) <= 1e-6 * peak
+
+
 def test_welch_csd_real_pair_equals_plain(E):
     import os
     rng = np.random.default_rng(8)
