@@ -102,6 +102,36 @@ __device__ __forceinline__ cf load_sample(const void *x, int64_t i, bool cplx) {
     return mk(reinterpret_cast<const float *>(x)[i], 0.f);
 }
 
+// write-once output streams (spectrograms, filtered signals): non-temporal stores (SP_NT_STORES=0 restores plain stores)
+#ifndef SP_NT_STORES
+#define SP_NT_STORES 1
+#endif
+typedef float sp_f2s __attribute__((ext_vector_type(2)));
+typedef float sp_f4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_stream(float *p, float v) {
+#if SP_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(cf *p, cf v) {
+#if SP_NT_STORES
+    const sp_f2s q = {v.x, v.y};
+    __builtin_nontemporal_store(q, reinterpret_cast<sp_f2s *>(p));
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(float4 *p, float4 v) {
+#if SP_NT_STORES
+    const sp_f4s q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<sp_f4s *>(p));
+#else
+    *p = v;
+#endif
+}
+
 // sum over the 64 lanes of a wave without the LDS pipe: xor-butterfly inside each row of 16 lanes with DPP (quad_perm
 // [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror -- after each step the partner groups hold equal values, so the mirrors
 // act as xor 4 / xor 8), then the four row sums through v_readlane.  The result is uniform.
@@ -281,7 +311,7 @@ __global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in,
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
                 const int i = tid + C::T * t;
-                if (X::EXACT || i < n) out[b * n + i] = mk(scl * v[t].x, sgn * scl * v[t].y);
+                if (X::EXACT || i < n) st_stream(out + b * n + i, mk(scl * v[t].x, sgn * scl * v[t].y));
             }
         }
     }
@@ -1887,15 +1917,15 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
                     const float hb = has_b ? a : 0.f;
                     // [pair][bin group of 8][channel slot of 64][bin in group][frame of the pair]: for one (pair, group) the
                     // 64 channels' 128-byte lines are 8 KiB contiguous -- what one tile row of k_csdm_bf16 streams
-                    reinterpret_cast<float4 *>(out)[((((ga / 2) * (int64_t)(nb / 8) + slot / 8) * 64 + blockIdx.y) * 8) + (slot & 7)] =
-                        make_float4(a * xa.x, a * xa.y, hb * xb.x, hb * xb.y);
+                    st_stream(reinterpret_cast<float4 *>(out) + ((((ga / 2) * (int64_t)(nb / 8) + slot / 8) * 64 + blockIdx.y) * 8) + (slot & 7),
+                              make_float4(a * xa.x, a * xa.y, hb * xb.x, hb * xb.y));
                 } else if (out_power) {
-                    reinterpret_cast<float *>(out)[ga * nb + slot] = amp * cnorm(xa);
-                    if (has_b) reinterpret_cast<float *>(out)[(ga + 1) * nb + slot] = amp * cnorm(xb);
+                    st_stream(reinterpret_cast<float *>(out) + ga * nb + slot, amp * cnorm(xa));
+                    if (has_b) st_stream(reinterpret_cast<float *>(out) + (ga + 1) * nb + slot, amp * cnorm(xb));
                 } else {
                     const float a = bin_doubled(k, N, sided) ? amp * 1.41421356237309504880f : amp;
-                    reinterpret_cast<cf *>(out)[ga * nb + slot] = a * xa;
-                    if (has_b) reinterpret_cast<cf *>(out)[(ga + 1) * nb + slot] = a * xb;
+                    st_stream(reinterpret_cast<cf *>(out) + ga * nb + slot, a * xa);
+                    if (has_b) st_stream(reinterpret_cast<cf *>(out) + (ga + 1) * nb + slot, a * xb);
                 }
             }
         }
@@ -2573,7 +2603,7 @@ __global__ __launch_bounds__(X::C::WG, SP_HILBERT_WAVES) void k_hilbert(const fl
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
                 const int k = tid + C::T * t;
-                if (X::EXACT || k < n) out[b * n + k] = mk(v[t].x * inv, -v[t].y * inv);
+                if (X::EXACT || k < n) st_stream(out + b * n + k, mk(v[t].x * inv, -v[t].y * inv));
             }
         }
     }
@@ -2647,8 +2677,8 @@ __global__ __launch_bounds__(WgCfg<N>::WG, 2) void k_fftfilt(const float *__rest
                 for (int t = 0; t < C::R; ++t) {
                     const int m = tid + C::T * t;
                     if (m >= P1) {
-                        y0[m] = v[t].x;
-                        y0[lb + m] = -v[t].y;                    // conj of the inverse trick
+                        st_stream(y0 + m, v[t].x);
+                        st_stream(y0 + lb + m, -v[t].y);         // conj of the inverse trick
                     }
                 }
             } else {
