@@ -28,6 +28,9 @@ namespace sp {
 #ifndef CB_FORM
 #define CB_FORM 6
 #endif
+#ifndef CB_NT_LOADS
+#define CB_NT_LOADS 1
+#endif
 #ifndef CB_INTERLEAVE
 #define CB_INTERLEAVE 5          // VALU instructions per MFMA in the scheduling pipeline (0: leave it to hipcc)
 #endif
@@ -132,7 +135,14 @@ static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__
         for (int q = 0; q < CB_FP; ++q) {
             const int64_t p = p0 + q;
             const bool ok = p < pend;
+#if CB_NT_LOADS
+            {
+                const sp_f4s r = __builtin_nontemporal_load(reinterpret_cast<const sp_f4s *>(rowbase + (ok ? p : pbeg) * pstride));
+                st[q] = make_float4(r.x, r.y, r.z, r.w);       // read exactly once
+            }
+#else
             st[q] = rowbase[(ok ? p : pbeg) * pstride];        // clamped address; masked at lstore
+#endif
             keep[q] = ok ? keepc : 0.f;
         }
     };
