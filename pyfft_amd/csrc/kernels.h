@@ -102,6 +102,26 @@ __device__ __forceinline__ cf load_sample(const void *x, int64_t i, bool cplx) {
     return mk(reinterpret_cast<const float *>(x)[i], 0.f);
 }
 
+// read-once input streams: non-temporal loads (SP_NT_STREAM_LOADS=0 restores plain loads)
+#ifndef SP_NT_STREAM_LOADS
+#define SP_NT_STREAM_LOADS 1
+#endif
+__device__ __forceinline__ float ld_stream(const float *p) {
+#if SP_NT_STREAM_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ cf ld_stream(const cf *p) {
+#if SP_NT_STREAM_LOADS
+    typedef float f2_ __attribute__((ext_vector_type(2)));
+    const f2_ r = __builtin_nontemporal_load(reinterpret_cast<const f2_ *>(p));
+    return mk(r.x, r.y);
+#else
+    return *p;
+#endif
+}
 // write-once output streams (spectrograms, filtered signals): non-temporal stores (SP_NT_STORES=0 restores plain stores)
 #ifndef SP_NT_STORES
 #define SP_NT_STORES 1
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in,
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int i = tid + C::T * t;
-            v[t] = in[bl * n + (X::EXACT || i < n ? i : n - 1)];
+            v[t] = ld_stream(in + bl * n + (X::EXACT || i < n ? i : n - 1));
         }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, sgn * v[t].y);
@@ -2636,7 +2656,7 @@ __global__ __launch_bounds__(WgCfg<N>::WG, 2) void k_fftfilt(const float *__rest
         if constexpr (!EDGE) {
             const float *b0 = x + s0;
 #pragma unroll
-            for (int t = 0; t < C::R; ++t) dst[t] = mk(b0[tid + C::T * t], b0[lb + tid + C::T * t]);
+            for (int t = 0; t < C::R; ++t) dst[t] = mk(ld_stream(b0 + tid + C::T * t), ld_stream(b0 + lb + tid + C::T * t));
         } else {
             const int64_t s1 = s0 + Lb;
 #pragma unroll
