@@ -1321,6 +1321,21 @@ static __global__ __launch_bounds__(1024) void k_op_estimate(const void *__restr
 #define SP_FIN_BINS 32
 #define SP_FIN_SLICES 32
 // sym != 0 (real-pair kernels): the bin sum is (S[k] + S[(n-k) % n]) / 2.
+// sum over the slices of the finish kernels' [NJ][slices][bins] image by halving (fixed order: deterministic); the result of
+// column `lane` is left in sh[j][0][lane].  (The first form let the 32 threads of slice 0 add 32 values each, fully unrolled:
+// k_csd_pair_finish spilled 268 VGPRs and took 0.39 ms for 100 MB of partial spectra.)
+template <int NJ>
+__device__ __forceinline__ void fin_reduce(double (&sh)[NJ][SP_FIN_SLICES][SP_FIN_BINS], int sl, int lane) {
+    for (int off = SP_FIN_SLICES / 2; off > 0; off >>= 1) {
+        __syncthreads();
+        if (sl < off) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) sh[j][sl][lane] += sh[j][sl + off][lane];
+        }
+    }
+    __syncthreads();
+}
+
 static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_welch_finish(const float *__restrict__ partial, int64_t G,
                                                                                      int L, int n, int sided, double scale,
                                                                                      double *__restrict__ out, int sym) {
@@ -1652,15 +1667,13 @@ static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_pair_
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) sh[j][sl][lane] = s[j];
-    __syncthreads();
+    fin_reduce<6>(sh, sl, lane);
     if (sl == 0 && k < n) {
         const int slot = bin_slot(k, n, sided);
         if (slot >= 0) {
-            double t[6] = {0, 0, 0, 0, 0, 0};
+            double t[6];
 #pragma unroll
-            for (int j = 0; j < 6; ++j)
-#pragma unroll
-                for (int q = 0; q < SP_FIN_SLICES; ++q) t[j] += sh[j][q][lane];
+            for (int j = 0; j < 6; ++j) t[j] = sh[j][0][lane];
             const double m = 0.5 * scale * (bin_doubled(k, n, sided) ? 2.0 : 1.0);
             pyy[(int64_t)ch * nb + slot] = (t[0] + t[1]) * m;
             pxy[((int64_t)ch * nb + slot) * 2] = (t[2] + t[4]) * m;
@@ -1692,15 +1705,13 @@ static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_rp_fi
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) sh[j][sl][lane] = s[j];
-    __syncthreads();
+    fin_reduce<4>(sh, sl, lane);
     if (sl == 0 && k < n) {
         const int slot = bin_slot(k, n, sided);
         if (slot >= 0) {
-            double t[4] = {0, 0, 0, 0};
+            double t[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < SP_FIN_SLICES; ++q) t[j] += sh[j][q][lane];
+            for (int j = 0; j < 4; ++j) t[j] = sh[j][0][lane];
             const double m = scale * (bin_doubled(k, n, sided) ? 2.0 : 1.0);
             if (ch == 0) pxx[slot] = 0.25 * (t[0] + t[1] + 2.0 * t[2]) * m;
             pyy[(int64_t)ch * nb + slot] = 0.25 * (t[0] + t[1] - 2.0 * t[2]) * m;
@@ -1730,15 +1741,13 @@ static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_finis
         }
 #pragma unroll
     for (int j = 0; j < 4; ++j) sh[j][sl][lane] = s[j];
-    __syncthreads();
+    fin_reduce<4>(sh, sl, lane);
     if (sl == 0 && k < n) {
         const int slot = bin_slot(k, n, sided);
         if (slot >= 0) {
-            double tot[4] = {0, 0, 0, 0};
+            double tot[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int q = 0; q < SP_FIN_SLICES; ++q) tot[j] += sh[j][q][lane];
+            for (int j = 0; j < 4; ++j) tot[j] = sh[j][0][lane];
             const double m = scale * (bin_doubled(k, n, sided) ? 2.0 : 1.0);
             if (ch == 0) pxx[slot] = tot[0] * m;
             pyy[(int64_t)ch * nb + slot] = tot[1] * m;
