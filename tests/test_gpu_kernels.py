@@ -413,7 +413,8 @@ def test_welch_csd_multichannel_twosided(E):
 
 
 @pytest.mark.parametrize("nch,nfft,hop,nsig", [(5, 256, 128, 6000), (64, 1024, 512, 20000), (70, 512, 256, 9000),
-                                                (3, 1000, 300, 7000)])
+                                                (3, 1000, 300, 7000), (3, 32, 16, 819), (64, 64, 32, 10688),
+                                                (2, 8192, 4096, 40960)])
 def test_csd_matrix(E, nch, nfft, hop, nsig):
     """cfg5 shape (reduced): common component with per-channel gain/delay + independent noise; full nch x nch matrix,
     including more than one 64-channel block, a ragged last frame chunk and a non power-of-two segment"""
