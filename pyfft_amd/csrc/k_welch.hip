@@ -191,16 +191,16 @@ int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, 
         if (export_state) {                                                                           \
             if (cplx)                                                                                 \
                 hipLaunchKernelGGL((k_op_finish<NN, true, true>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, \
-                                   x, trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out); \
+                                   x, trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out, st.sym); \
             else                                                                                      \
                 hipLaunchKernelGGL((k_op_finish<NN, false, true>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, \
-                                   x, trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out); \
+                                   x, trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out, st.sym); \
         } else if (cplx)                                                                              \
             hipLaunchKernelGGL((k_op_finish<NN, true>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
-                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out); \
+                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out, st.sym); \
         else                                                                                          \
             hipLaunchKernelGGL((k_op_finish<NN, false>), dim3(1), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
-                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out); \
+                               trend, win, st.Sl, st.A, Wf, st.dlt, mean_in, H, r, nframes, nmean, sided, scale, xf.tb, out, st.sym); \
         break;
     switch (xf.L) {
         FIN_(256) FIN_(512) FIN_(1024) FIN_(2048) FIN_(4096) FIN_(8192)

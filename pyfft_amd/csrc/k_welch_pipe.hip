@@ -14,6 +14,7 @@
 // (same arithmetic in the same order per frame; the partition into groups differs).
 // Reference path: fft_analysis.py:2126-2203 fft_win -> :1946 Pstft -> :1980 averagewins.
 #include "launch.h"
+#include <type_traits>
 // SP_PIPE_ES=1: the 16 scatter stores of a pass leave 4 at a time behind the radix-4 butterfly that produces them
 #ifndef SP_PIPE_ES
 #define SP_PIPE_ES 1
@@ -40,12 +41,15 @@
 namespace sp {
 
 #if !SP_PACKED
-template <bool CPLX, int SHIFT, int MODE>      // MODE 0: plain accumulation, 1: one-pass mean detrend, 2: moments per frame (cog)
+template <bool CPLX, int SHIFT, int MODE>      // MODE 0: plain accumulation, 1: one-pass mean detrend, 2: moments per frame (cog),
+                                               // 3 / 4: the same as 0 / 1 for real input with two frames per transform
 __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, const float *__restrict__ win,
                                                      int64_t nframes, int64_t fpg, float *__restrict__ trend, XfTables tb,
                                                      float *__restrict__ partial, cf *__restrict__ spartial) {
     constexpr int N = 4096;
-    constexpr bool ONEPASS = MODE == 1, COG = MODE == 2;
+    constexpr bool RP = MODE >= 3;           // real input, two frames per transform (modes 3: plain, 4: one-pass detrend)
+    constexpr bool ONEPASS = MODE == 1 || MODE == 4, COG = MODE == 2;
+    static_assert(!RP || (!CPLX && SHIFT == 8), "the real-pair form is for real input at hop = nfft / 2");
     using PL = FftPlan<N>;
     using F = WgFft<N>;
     constexpr int T = PL::T, R = PL::R, KEEP = R - SHIFT, IMG = PL::LDS_ELEMS;
@@ -98,9 +102,9 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
         mu = load_trend(trend).m;          // the caller's constant (or zero): plain accumulation, no epilogue
     }
     const int64_t gid = blockIdx.x;
-    const int64_t g0 = gid * fpg;
+    const int64_t g0 = gid * fpg;                        // first frame (RP: first frame PAIR) of this workgroup
     const int64_t last = nframes - 1;
-    int64_t trips = nframes - g0;
+    int64_t trips = (RP ? (nframes + 1) / 2 : nframes) - g0;
     trips = trips < 0 ? 0 : (trips > fpg ? fpg : trips);
 #if SP_PIPE_TIMING
     // diagnostic: per role, cycles between leaving a barrier and arriving at the next one (busy) and cycles spent at the barrier
@@ -121,7 +125,97 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
     const int64_t periods = trips + DRAIN;
     F f;
 
-    if (role == 0) {
+    if (role == 0 && RP) {
+        // real input, frames 2q and 2q + 1 in one transform: z = f_2q + i f_2q+1 (the finish kernel symmetrises |Z|^2).  At hop
+        // = N/2 the pair q needs the chunk q = samples [q N, q N + N) as its real part and [second half of chunk q | first half
+        // of chunk q + 1] as its imaginary part: every sample is loaded once, 16 floats per thread and period, one period
+        // before it is first used (three register sets rotate: current, next, incoming)
+        const float *xr = reinterpret_cast<const float *>(x);
+        float m = mu.x;
+        asm volatile("" : "+v"(m));
+        float w[R], sacc[SHIFT];
+#pragma unroll
+        for (int t = 0; t < R; ++t) w[t] = win[tid + T * t];
+#pragma unroll
+        for (int s = 0; s < SHIFT; ++s) sacc[s] = 0.f;
+        // chunk q, clamped per half to a half that exists (first half: 2q <= nframes, second: 2q + 1 <= nframes)
+        auto issue_chunk = [&](float (&dst)[R], int64_t q) __attribute__((always_inline)) {
+            const int64_t q1 = 2 * q <= nframes ? q : 0, q2 = 2 * q + 1 <= nframes ? q : 0;
+            const float *b1 = xr + q1 * (int64_t)N, *b2 = xr + q2 * (int64_t)N;
+#pragma unroll
+            for (int t = 0; t < R; ++t) {
+                const unsigned off = (unsigned)(tid + T * t);
+#if SP_PIPE_NT
+                dst[t] = __builtin_nontemporal_load((t < R / 2 ? b1 : b2) + off);
+#else
+                dst[t] = (t < R / 2 ? b1 : b2)[off];
+#endif
+            }
+        };
+        float ca[R], cb[R], cc[R];
+        issue_chunk(ca, g0);
+        issue_chunk(cb, g0 + 1);
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            ca[t] -= m;
+            cb[t] -= m;
+        }
+        // hb: frame 2q + 1 exists (false only for the last pair of an odd frame count, which the tail loop below handles)
+        auto frame = [&](auto hb, int64_t i, cf *img, float (&cur)[R], float (&nxt)[R], float (&fill)[R]) __attribute__((always_inline)) {
+            constexpr bool HB = decltype(hb)::value;
+            issue_chunk(fill, g0 + i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            cf v[R];
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = mk(w[t] * cur[t], HB ? w[t] * (t < R / 2 ? cur[t + R / 2] : nxt[t - R / 2]) : 0.f);
+            f.template bfly_scatter<0>(v, img, tid);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ONEPASS) {
+                // last hop-block of frame 2q (second half of the chunk) and of frame 2q + 1 (first half of the next one)
+#pragma unroll
+                for (int s = 0; s < SHIFT; ++s) sacc[s] += HB ? cur[R / 2 + s] + nxt[s] : cur[R / 2 + s];
+            }
+#pragma unroll
+            for (int t = 0; t < R; ++t) fill[t] -= m;
+        };
+        const std::true_type yes;
+        const std::false_type no;
+        int64_t i = 0;
+        for (; i + 6 < trips; i += 6) {                           // (never the last pair: the tail loop owns it)
+            frame(yes, i, imgA, ca, cb, cc);
+            PIPE_SYNC();
+            frame(yes, i + 1, imgA + IMG, cb, cc, ca);
+            PIPE_SYNC();
+            frame(yes, i + 2, imgA, cc, ca, cb);
+            PIPE_SYNC();
+            frame(yes, i + 3, imgA + IMG, ca, cb, cc);
+            PIPE_SYNC();
+            frame(yes, i + 4, imgA, cb, cc, ca);
+            PIPE_SYNC();
+            frame(yes, i + 5, imgA + IMG, cc, ca, cb);
+            PIPE_SYNC();
+        }
+        for (; i < trips; ++i) {                                  // i is a multiple of 6 at entry: the rotation state is i % 3
+            cf *img = (i & 1) ? imgA + IMG : imgA;
+            const bool has_b = 2 * (g0 + i) + 1 < nframes;        // uniform
+            if (has_b) {
+                if (i % 3 == 0) frame(yes, i, img, ca, cb, cc);
+                else if (i % 3 == 1) frame(yes, i, img, cb, cc, ca);
+                else frame(yes, i, img, cc, ca, cb);
+            } else {
+                if (i % 3 == 0) frame(no, i, img, ca, cb, cc);
+                else if (i % 3 == 1) frame(no, i, img, cb, cc, ca);
+                else frame(no, i, img, cc, ca, cb);
+            }
+            PIPE_SYNC();
+        }
+#pragma unroll
+        for (int d = 0; d < DRAIN; ++d) PIPE_SYNC();
+        if constexpr (ONEPASS) {
+#pragma unroll
+            for (int s = 0; s < SHIFT; ++s) spartial[gid * hop + tid + T * s] = mk(sacc[s], 0.f);
+        }
+    } else if (role == 0) {
         if constexpr (SP_PIPE_PRIO) __builtin_amdgcn_s_setprio((SP_PIPE_PRIO / 100) % 10);
         // keep the constant in VGPRs (an SGPR source halves the VALU issue rate on gfx950)
         asm volatile("" : "+v"(mu.x), "+v"(mu.y));
@@ -356,7 +450,8 @@ bool welch_pipe_eligible(const Xf &xf, int hop) {
 #endif
 }
 
-// mode 2: `partial` is the cog slot array [4][nframes] of (num, den) pairs (spartial unused)
+// mode 2: `partial` is the cog slot array [4][nframes] of (num, den) pairs (spartial unused); mode 3: real input, two
+// frames per transform (rp partitions frame PAIRS; spartial != null: one-pass block sums as well)
 int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, float *trend,
                       const Xf &xf, float *partial, const RunPart &rp, cf *spartial, int mode) {
 #if SP_PACKED
@@ -377,7 +472,10 @@ int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, i
     const int shift = hop / 256;
 #define PIPE_S_(CP, OP)                                                                               \
     if (shift == 8) PIPE_(CP, 8, OP) else if (shift == 4) PIPE_(CP, 4, OP) else PIPE_(CP, 16, OP)
-    if (mode == 2) {
+    if (mode == 3) {
+        if (cplx || shift != 8) return -1;
+        if (spartial) PIPE_(false, 8, 4) else PIPE_(false, 8, 3)
+    } else if (mode == 2) {
         if (cplx) { PIPE_S_(true, 2) } else { PIPE_S_(false, 2) }
     } else if (spartial) {
         if (cplx) { PIPE_S_(true, 1) } else { PIPE_S_(false, 1) }

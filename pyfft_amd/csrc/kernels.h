@@ -990,6 +990,7 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_carry_cog(
 // state layout (doubles): A[N] | Sl[2*H] | tot[2] = sum_{i<nmean}(x[i]-mu0) | dlt[2] = mean - mu0 | cnt[1]
 struct OnePass {
     double *A, *Sl, *tot, *dlt;
+    int sym = 0;       // 1: A holds sum |Z|^2 of real-pair transforms (Z = X_2q + i X_2q+1): sum |X|^2 [k] = (A[k] + A[N-k]) / 2
 };
 
 // column sums, in double, of two float matrices with G rows in ONE launch: m0[G][c0] -> o0[c0] (the raw |X|^2 sums
@@ -1097,7 +1098,7 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
                                                                     const double *__restrict__ dlt_local,
                                                                     const double *__restrict__ mean_in, int H, int r,
                                                                     int64_t M, int64_t nmean, int sided, double scale,
-                                                                    XfTables tb, double *__restrict__ out) {
+                                                                    XfTables tb, double *__restrict__ out, int sym) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
@@ -1110,7 +1111,7 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
 #pragma unroll
     for (int t = 0; t < C::R; ++t) {
         const int k = tid + C::T * t;
-        a_pre[t] = A[k];
+        a_pre[t] = sym ? 0.5 * (A[k] + A[(N - k) & (N - 1)]) : A[k];
         wf_pre[t] = Wf[k];
         win_pre[t] = win[k];
     }

@@ -638,8 +638,12 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     // its own trend record: calls between sp_welch_accum and sp_welch_finish reuse the shared one
     if (g.pend_trend.ensure(256)) return -1;
     TrendBuf tb{(float *)g.pend_trend.p, nullptr};
-    const bool pipe = welch_pipe_wanted(xf, hop, nframes);
-    const RunPart rp = pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc()) : run_partition(xf.L, nframes, g.ncu);
+    // real input at hop = nfft/2: two frames per transform on the pipeline (k_welch_pipe modes 3/4), partitioned over frame PAIRS
+    const bool realpair = !cplx && 2 * hop == nfft && nframes >= 2 && !env_flag("SP_NO_REALPAIR") &&
+                          welch_pipe_wanted(xf, hop, (nframes + 1) / 2);
+    const bool pipe = realpair || welch_pipe_wanted(xf, hop, nframes);
+    const RunPart rp = realpair ? run_partition(xf.L, (nframes + 1) / 2, g.ncu, welch_pipe_gpc())
+                                : (pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc()) : run_partition(xf.L, nframes, g.ncu));
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
     const size_t sp_bytes = sizeof(cf) * (size_t)rp.groups * (size_t)hop;
     const size_t st_doubles = (size_t)nfft + 2 * (size_t)hop + 8;
@@ -663,10 +667,12 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
 #else
     (void)est;                       // the main kernel estimates mu0 itself and publishes it in tb.f
 #endif
+    st.sym = realpair ? 1 : 0;
     if (pipe) {
         ProfScope ps;
-        LAUNCHCHK(launch_welch_pipe(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, spartial));
-        g.last_kernel = "k_welch_pipe(onepass)";
+        LAUNCHCHK(launch_welch_pipe(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, spartial,
+                                    realpair ? 3 : 0));
+        g.last_kernel = realpair ? "k_welch_pipe(onepass,realpair)" : "k_welch_pipe(onepass)";
     } else {
         ProfScope ps;
         LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,
@@ -931,8 +937,10 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         }
         LAUNCHCHK(launch_long_finish(lc(), acc, nfft, sided, scale / (double)nframes, false, out_d));
         g.last_kernel = "k_long_acc_psd";
-    } else if (cplx && detrend == SP_DETREND_MEAN && allow_carry && !env_flag("SP_WELCH_TWOPASS") &&
-        welch_carry_eligible(xf, hop, false)) {
+    } else if (detrend == SP_DETREND_MEAN && allow_carry && !segmean && !env_flag("SP_WELCH_TWOPASS") &&
+               welch_carry_eligible(xf, hop, false) &&
+               (cplx || (2 * hop == nfft && nframes >= 2 && !env_flag("SP_NO_REALPAIR") &&
+                         welch_pipe_wanted(xf, hop, (nframes + 1) / 2)))) {
         // global-mean detrend in ONE pass over the signal (estimate + exact correction in the epilogue)
         if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nsig, false)) return -1;
         if (welch_finish_locked(nullptr, nframes, sided, scale, out_d)) return -1;
@@ -944,13 +952,18 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_re, mean_im)) return -1;
         const bool pair = !cplx && nframes >= 2 && !segmean && !env_flag("SP_NO_REALPAIR");
         const bool pipe = !pair && !segmean && detrend != 2 && allow_carry && welch_pipe_wanted(xf, hop, nframes);
-        const RunPart rp = pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc())
-                                : run_partition(xf.L, pair ? (nframes + 1) / 2 : nframes, g.ncu);
+        const bool pipe_rp = pair && detrend != 2 && allow_carry && 2 * hop == nfft && welch_pipe_wanted(xf, hop, (nframes + 1) / 2);
+        const RunPart rp = pipe_rp ? run_partition(xf.L, (nframes + 1) / 2, g.ncu, welch_pipe_gpc())
+                                   : (pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc())
+                                           : run_partition(xf.L, pair ? (nframes + 1) / 2 : nframes, g.ncu));
         if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
         float *partial = (float *)g.work.p;
         {
             ProfScope ps;
-            if (pair) {
+            if (pipe_rp) {
+                LAUNCHCHK(launch_welch_pipe(lc(), xd, false, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, nullptr, 3));
+                g.last_kernel = "k_welch_pipe(realpair)";
+            } else if (pair) {
                 // real input: two frames per complex transform, |Z|^2 accumulated, symmetrised by the finish kernel
                 LAUNCHCHK(launch_welch_rp(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf,
                                           partial, rp));

@@ -47,6 +47,19 @@ for hop, M in ((2048, 333), (1024, 64), (4096, 7)):
     ref = O.welch_psd_stream((s - np.complex64(mv)).astype(np.complex64), win, nfft, hop, M, 1.0, detrend_style=0)
     err = float(np.max(np.abs(p - ref) / (2e-4 * np.abs(ref) + 1e-6 * ref.max())))
     assert err <= 1.0, ("const", hop, M, err)
+# real input at hop = nfft/2: two frames per transform (modes 3 / 4), even and odd frame counts, all detrend forms
+for M in (2, 3, 8, 9, 500, 1001):
+    n = (M - 1) * 2048 + nfft + 5
+    s = (rng.standard_normal(n) + 1.7).astype(np.float32)
+    for det, mv in ((True, None), (False, None), (True, 1.5)):
+        p = E.welch_psd(s, win, 2048, M, detrend=det, mean_value=mv, sided=E.SIDED_TWO, scale=1.0 / S2)
+        assert "realpair" in E.profile_last_kernel(), (E.profile_last_kernel(), M, det, mv)
+        sr = s if mv is None else (s - np.float32(mv))
+        ref = O.welch_psd_stream(sr, win, nfft, 2048, M, 1.0, detrend_style=1 if (det and mv is None) else 0)
+        err = float(np.max(np.abs(p - ref) / (2e-4 * np.abs(ref) + 1e-6 * ref.max())))
+        assert err <= 1.0, ("realpair", M, det, mv, err)
+    p1 = E.welch_psd(s, win, 2048, M, detrend=True, sided=E.SIDED_ONE, scale=1.0 / S2)
+    assert p1.shape[0] in (nfft // 2, nfft // 2 + 1) and np.all(np.isfinite(p1))
 # centre of gravity per frame (Doppler.cog / cogspec): the back role reduces each frame's moments instead of summing |X|^2
 fs = 1.0e3
 for hop, M in ((2048, 200), (1024, 131), (4096, 65)):
