@@ -26,6 +26,21 @@ int launch_stft(LaunchCtx c, const void *x, bool cplx, const float *win, int hop
 int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
                    const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg, int nchan,
                    int64_t x_cs, int64_t out_cs, int out_ld) {
+    // register-carried overlap (k_stft_rp<.., SHIFT>) for the long transforms at 75 % overlap without linear detrend: -5..-10 %
+    // (tools/stftcarry_ab.py; at 50 % overlap the same form measured 40 % SLOWER than the plain double fetch and is not used)
+    const int T_ = xf.L / 16;
+    const int shift = (!lin && xf.L >= 1024 && hop % T_ == 0 && hop / T_ == 4 && !getenv("SP_STFT_NOCARRY")) ? 4 : 0;
+#define RPS_(NN, S)                                                                                   \
+    hipLaunchKernelGGL((k_stft_rp<NN, false, S>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
+                       win, hop, nframes, rp.fpg, trend, xf.tb, sided, amp, out_power, out, pseg, x_cs, out_cs, out_ld)
+#define RPC_(NN)                                                                                      \
+    case NN:                                                                                          \
+        if (shift == 4) RPS_(NN, 4);                                                                  \
+        else if (lin) hipLaunchKernelGGL((k_stft_rp<NN, true>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG),     \
+                                         WgCfg<NN>::lds_bytes(1), c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, sided, \
+                                         amp, out_power, out, pseg, x_cs, out_cs, out_ld);            \
+        else RPS_(NN, 0);                                                                             \
+        break;
 #define RP_(NN)                                                                                       \
     case NN:                                                                                          \
         if (lin) hipLaunchKernelGGL((k_stft_rp<NN, true>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG),          \
@@ -36,10 +51,12 @@ int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64
                                 out_power, out, pseg, x_cs, out_cs, out_ld);                          \
         break;
     switch (xf.L) {
-        RP_(32) RP_(64) RP_(128) RP_(256) RP_(512) RP_(1024) RP_(2048) RP_(4096) RP_(8192)
+        RP_(32) RP_(64) RP_(128) RP_(256) RP_(512) RPC_(1024) RPC_(2048) RPC_(4096) RPC_(8192)
         default: return -1;
     }
 #undef RP_
+#undef RPC_
+#undef RPS_
     return 0;
 }
 

@@ -1864,7 +1864,10 @@ static __global__ void k_cog_finish(const cf *__restrict__ acc, int wpf, int64_t
 // X_{g+1} = (Z[k] - conj Z[n-k]) / (2i).  The mirror comes from one more LDS exchange (linear image, reversed read).
 // Power-of-two n only (mirror index by masking); the other lengths use k_stft.
 // blockIdx.y = channel: x += y*x_cs samples, out += y*out_cs elements, trend += 4*y (pseg only for one channel)
-template <int N, bool LIN>
+// SHIFT > 0 (hop = SHIFT * T, a whole number of register slots): the samples are carried in registers from pair to pair --
+// frame b is frame a shifted by SHIFT slots and the next pair starts 2 SHIFT slots on, so only 2 SHIFT new slots per thread
+// and pair are loaded (8 instead of 32 at 75 % overlap), one pair ahead of their use; every sample is loaded once.
+template <int N, bool LIN, int SHIFT = 0>
 __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restrict__ x, const float *__restrict__ win,
                                                            int hop, int64_t nframes, int64_t ppg,
                                                            const float *__restrict__ trend, XfTables tb, int sided,
@@ -1894,8 +1897,36 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
 #pragma unroll
         for (int t = 0; t < C::R; ++t) dst[t] = mk(x[base_a + tid + C::T * t], x[base_b + tid + C::T * t]);
     };
-    cf nxt[C::R];
-    fetch(p0, nxt);
+    constexpr int RS = C::R + SHIFT;                      // slots held: frame a = 0..R-1, frame b = SHIFT..R+SHIFT-1
+    const int64_t span = (nframes - 1) * (int64_t)hop + n;
+    float ring[SHIFT > 0 ? RS : 1], inc[SHIFT > 0 ? 2 * SHIFT : 1];
+    // new slots of pair q (those pair q - 1 does not hold), clamped to the signal
+    auto fetch_new = [&](int64_t q) __attribute__((always_inline)) {
+        const int64_t b0 = 2 * q * (int64_t)hop + (int64_t)C::T * (RS - 2 * SHIFT);      // uniform
+        if (b0 + (int64_t)C::T * 2 * SHIFT <= span) {
+            const float *xb = x + b0;                            // whole range inside the signal: scalar base + lane offset
+#pragma unroll
+            for (int j = 0; j < 2 * SHIFT; ++j) inc[j] = xb[tid + C::T * j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2 * SHIFT; ++j) {
+                const int64_t idx = b0 + tid + (int64_t)C::T * j;
+                inc[j] = x[idx < span ? idx : span - 1];
+            }
+        }
+    };
+    cf nxt[SHIFT > 0 ? 1 : C::R];
+    if constexpr (SHIFT > 0) {
+        const int64_t b = 2 * p0 * (int64_t)hop + tid;
+#pragma unroll
+        for (int s = 0; s < RS; ++s) {
+            const int64_t idx = b + (int64_t)C::T * s;
+            ring[s] = x[idx < span ? idx : span - 1];
+        }
+        fetch_new(p0 + 1);
+    } else {
+        fetch(p0, nxt);
+    }
     for (int64_t i = 0; i < ppg; ++i) {
         const int64_t p = p0 + i;
         const bool act = p < npairs;
@@ -1904,9 +1935,20 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restric
         const int64_t base_a = ga * hop, base_b = (has_b ? ga + 1 : ga) * hop;
         cf v[C::R];
         float pwa = 0.f, pwb = 0.f;
+        if constexpr (SHIFT > 0) {
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) v[t] = nxt[t];
-        fetch(p + 1, nxt);
+            for (int t = 0; t < C::R; ++t) v[t] = mk(ring[t], ring[t + SHIFT]);
+            // advance to pair p + 1 (its new slots arrived during the previous pair), then ask for those of pair p + 2
+#pragma unroll
+            for (int s = 0; s < RS - 2 * SHIFT; ++s) ring[s] = ring[s + 2 * SHIFT];
+#pragma unroll
+            for (int j = 0; j < 2 * SHIFT; ++j) ring[RS - 2 * SHIFT + j] = inc[j];
+            fetch_new(p + 2);
+        } else {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) v[t] = nxt[t];
+            fetch(p + 1, nxt);
+        }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int j = tid + C::T * t;
