@@ -203,7 +203,9 @@ template <bool LIN> __device__ __forceinline__ cf detrended(cf a, const Trend &t
     using C = typename X::C;                                                                          \
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];                          \
     cf *smem = reinterpret_cast<cf *>(smem_raw);                                                      \
-    const int grp = C::FPW == 1 ? 0 : (int)threadIdx.x / C::T;                                        \
+    /* T >= 64: a wave never straddles two groups -> the group index is wave-uniform: keep it (and every frame / row    \
+       base derived from it) in SGPRs instead of 64-bit VGPR arithmetic */                                            \
+    const int grp = C::FPW == 1 ? 0 : ((C::T % 64) == 0 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x / C::T) : (int)threadIdx.x / C::T); \
     const int tid = C::FPW == 1 ? (int)threadIdx.x : (int)threadIdx.x % C::T;                        \
     cf *lds = smem + grp * C::LDS_PER;                                                                \
     const int n = X::EXACT ? X::L : tb.n;                                                             \
@@ -1867,8 +1869,11 @@ static __global__ void k_cog_finish(const cf *__restrict__ acc, int wpf, int64_t
 // SHIFT > 0 (hop = SHIFT * T, a whole number of register slots): the samples are carried in registers from pair to pair --
 // frame b is frame a shifted by SHIFT slots and the next pair starts 2 SHIFT slots on, so only 2 SHIFT new slots per thread
 // and pair are loaded (8 instead of 32 at 75 % overlap), one pair ahead of their use; every sample is loaded once.
+#ifndef SP_STFT_MINWAVES
+#define SP_STFT_MINWAVES 1
+#endif
 template <int N, bool LIN, int SHIFT = 0>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_stft_rp(const float *__restrict__ x, const float *__restrict__ win,
+__global__ __launch_bounds__(WgCfg<N>::WG, SP_STFT_MINWAVES) void k_stft_rp(const float *__restrict__ x, const float *__restrict__ win,
                                                            int hop, int64_t nframes, int64_t ppg,
                                                            const float *__restrict__ trend, XfTables tb, int sided,
                                                            float amp, int out_power, void *__restrict__ out,
