@@ -43,12 +43,20 @@ namespace sp {
 #if !SP_PACKED
 template <bool CPLX, int SHIFT, int MODE>      // MODE 0: plain accumulation, 1: one-pass mean detrend, 2: moments per frame (cog),
                                                // 3 / 4: the same as 0 / 1 for real input with two frames per transform
-__global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, const float *__restrict__ win,
-                                                     int64_t nframes, int64_t fpg, float *__restrict__ trend, XfTables tb,
-                                                     float *__restrict__ partial, cf *__restrict__ spartial) {
+__global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_in, const float *__restrict__ win,
+                                                     int64_t nframes, int64_t fpg, float *__restrict__ trend_in, XfTables tb,
+                                                     float *__restrict__ partial, cf *__restrict__ spartial, int64_t x_cs, int gpr) {
     constexpr int N = 4096;
-    constexpr bool RP = MODE >= 3;           // real input, two frames per transform (modes 3: plain, 4: one-pass detrend)
+    constexpr bool RP = MODE >= 3;           // real input, two frames per transform (modes 3: plain, 4: one-pass detrend, 5: spectra)
     constexpr bool ONEPASS = MODE == 1 || MODE == 4, COG = MODE == 2;
+    // mode 5: no accumulation -- the packed pair spectrum Z = X_2q + i X_2q+1 of every frame pair is WRITTEN, for the CSD-matrix
+    // contraction (k_csdm_bf16<ZM>), as Zs[pair][group of 8 bins][channel slot of 64][2][8]: the 8 bins k of a group in the
+    // first half of a 128-byte line, their mirrors Z[N-k] in the second (the reader forms X_2q = (Z + conj Zm)/2 and
+    // X_2q+1 = (Z - conj Zm)/(2i) itself: no mirror exchange here).  blockIdx.y = channel (x_cs samples apart, trend record
+    // 4 y), gpr = bin groups per row.
+    constexpr bool SPEC = MODE == 5;
+    const void *x = SPEC ? (const void *)(reinterpret_cast<const float *>(x_in) + (int64_t)blockIdx.y * x_cs) : x_in;
+    float *trend = SPEC ? trend_in + 4 * blockIdx.y : trend_in;
     static_assert(!RP || (!CPLX && SHIFT == 8), "the real-pair form is for real input at hop = nfft / 2");
     using PL = FftPlan<N>;
     using F = WgFft<N>;
@@ -375,6 +383,11 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
         float acc[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) acc[t] = 0.f;
+        // SPEC: offset (complex elements) of bin k = tid + T t inside a pair's block, (kk / 8) 1024 + 8 h + kk % 8 with kk = k
+        // (h = 0) for k <= N/2 and kk = N - k (h = 1) above: t < 8: zlo + 32768 t; t > 8: zhi - 32768 (t - 8); t = 8: bin N/2 + tid
+        const unsigned zlo = (unsigned)((tid >> 3) * 1024 + (tid & 7));
+        const unsigned zhi = (unsigned)((((N / 2 - tid) >> 3) * 1024) + 8 + ((N / 2 - tid) & 7));
+        const unsigned z8 = tid == 0 ? (unsigned)((N / 16) * 1024) : zhi;
         cf va[R], vb[R];
         // COG (Doppler.cog / cogspec, Doppler.py:43-81): instead of summing |X|^2 over the frames, every frame's moments
         // sum ks |X|^2, sum |X|^2 (signed bin index ks, every bin) are reduced across the wave; a wave keeps the moments of its
@@ -396,7 +409,17 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
             }
             if (p >= 4 && p <= trips + 3) {
                 f.template bfly<2>(use, tid);
-                if constexpr (COG) {
+                if constexpr (SPEC) {
+                    // pair block base (uniform): pair * gpr * 1024 + channel * 16 complex elements
+                    cf *zb = reinterpret_cast<cf *>(partial) + ((g0 + (p - 4)) * (int64_t)gpr * 1024 + (int64_t)blockIdx.y * 16);
+                    unsigned bl = zlo, bh = zhi;
+                    asm volatile("" : "+v"(bl), "+v"(bh));          // (keeps hipcc from holding sixteen offsets in registers)
+#pragma unroll
+                    for (int t = 0; t < R; ++t) {
+                        const unsigned o = t < 8 ? bl + 32768u * t : (t == 8 ? z8 : bh - 32768u * (t - 8));
+                        st_stream(zb + o, use[t]);
+                    }
+                } else if constexpr (COG) {
                     // ks = tid + c_t with c_t = T t - (N in the upper half): sum ks p = tid sum p + sum c_t p
                     float numc = 0.f, den = 0.f;
 #pragma unroll
@@ -422,7 +445,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x, 
             step(va, vb, p, imgB + IMG);
             if (p + 1 < periods) step(vb, va, p + 1, imgB);
         }
-        if constexpr (!COG) {
+        if constexpr (!COG && !SPEC) {
 #pragma unroll
             for (int t = 0; t < R; ++t) partial[gid * N + tid + T * t] = acc[t];
         }
@@ -452,8 +475,10 @@ bool welch_pipe_eligible(const Xf &xf, int hop) {
 
 // mode 2: `partial` is the cog slot array [4][nframes] of (num, den) pairs (spartial unused); mode 3: real input, two
 // frames per transform (rp partitions frame PAIRS; spartial != null: one-pass block sums as well)
+// mode 5: `partial` receives the packed pair spectra of nch channels (x_cs samples apart; trend records 4 floats apart),
+// gpr bin groups per row (k_welch_pipe, SPEC)
 int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, float *trend,
-                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial, int mode) {
+                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial, int mode, int nch, int64_t x_cs, int gpr) {
 #if SP_PACKED
     return -1;
 #else
@@ -466,13 +491,17 @@ int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, i
                 return -1;                                                                            \
             once = true;                                                                              \
         }                                                                                             \
-        hipLaunchKernelGGL((k_welch_pipe<CP, S, OP>), dim3(rp.blocks), dim3(768), lds, c.stream, x, win, nframes, rp.fpg, trend, \
-                           xf.tb, partial, spartial);                                                 \
+        hipLaunchKernelGGL((k_welch_pipe<CP, S, OP>), dim3(rp.blocks, gy), dim3(768), lds, c.stream, x, win, nframes, rp.fpg, trend, \
+                           xf.tb, partial, spartial, x_cs, gpr);                                      \
     }
     const int shift = hop / 256;
+    const unsigned gy = mode == 5 ? (unsigned)nch : 1u;
 #define PIPE_S_(CP, OP)                                                                               \
     if (shift == 8) PIPE_(CP, 8, OP) else if (shift == 4) PIPE_(CP, 4, OP) else PIPE_(CP, 16, OP)
-    if (mode == 3) {
+    if (mode == 5) {
+        if (cplx || shift != 8 || nch < 1 || gpr < 1) return -1;
+        PIPE_(false, 8, 5)
+    } else if (mode == 3) {
         if (cplx || shift != 8) return -1;
         if (spartial) PIPE_(false, 8, 4) else PIPE_(false, 8, 3)
     } else if (mode == 2) {

@@ -124,7 +124,8 @@ int launch_welch(LaunchCtx c, const void *x, bool cplx, const float *win, int ho
                  const char **kname, int segmean = 0);
 bool welch_pipe_eligible(const Xf &xf, int hop);
 int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, int hop, int64_t nframes, float *trend,
-                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial, int mode = 0);
+                      const Xf &xf, float *partial, const RunPart &rp, cf *spartial, int mode = 0, int nch = 1, int64_t x_cs = 0,
+                      int gpr = 0);
 int launch_op_estimate(LaunchCtx c, const void *x, bool cplx, int64_t nsig, double *part, float *trend);
 int launch_op_reduce(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *partial, const cf *spartial,
                      int64_t G, const Xf &xf, int hop, int64_t nframes, int64_t nmean, OnePass st, double *sum_out);
@@ -167,7 +168,7 @@ int launch_csdm_gemm(LaunchCtx c, const cf *Xt, int nch, int64_t mc, int nb, dou
 int launch_csdm_finish(LaunchCtx c, double *G, int nch, int nb, double scale, int blk);
 int launch_csdm_transpose_kgc(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int nchp, int64_t m, int64_t mp, int nb);
 int launch_csdm_mfma(LaunchCtx c, const cf *Xt, int nch, int nchp, int64_t mp, int nb, double *G);
-int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld);
+int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld, int zm = 0);
 int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld = 0);
 int launch_hilbert_mid(LaunchCtx c, cf *Z, int64_t M, BigTw bt);
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out,

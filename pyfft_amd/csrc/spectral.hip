@@ -1321,6 +1321,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     cf *Xs = (cf *)g.cmS.p, *Xt = (cf *)g.cmT.p;
     for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
         const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
+        int spec_zm = 0;
         hipLaunchKernelGGL(k_trend_shift, dim3((nch + 63) / 64), dim3(64), 0, g.stream, tb.f, tb.f + 4 * nch, nch,
                            (double)f0 * (double)hop);
         if (lng) {
@@ -1333,6 +1334,21 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                     return -1;
                 LAUNCHCHK(launch_long_stft_out(lc(), S, m, nfft, SP_SIDED_HALF, 1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)ld, 0, ld));
             }
+        } else if (use_bf16 && nfft == 4096 && 2 * hop == nfft && detrend != 2 && (m + 1) / 2 >= 32 * (int64_t)((g.ncu + nch - 1) / nch) &&
+                   welch_pipe_wanted(xf, hop, (int64_t)1 << 40) && env_flag("SP_CSDM_PIPESPEC")) {
+            // experiment, off by default (SP_CSDM_PIPESPEC=1): the spectra stage as the pipeline of specialised waves
+            // (k_welch_pipe mode 5) -- it writes the PACKED pair spectra and needs no mirror exchange; the contraction splits them
+            // while loading (k_csdm_bf16<ZM>).  Correct, but 3.9 ms against k_stft_rp's 2.9: a bin and its mirror live in
+            // different threads, so each 128-byte line [8 bins | 8 mirrors] is written in two 64-byte halves by different stores
+            const int64_t pairs = (m + 1) / 2;
+            const int runs = (g.ncu + nch - 1) / nch > 0 ? (g.ncu + nch - 1) / nch : 1;
+            RunPart rp;
+            rp.fpg = (pairs + runs - 1) / runs;
+            rp.blocks = (int)((pairs + rp.fpg - 1) / rp.fpg);
+            rp.groups = rp.blocks;
+            LAUNCHCHK(launch_welch_pipe(lc(), xd + (size_t)f0 * (size_t)hop, false, (const float *)win_d, hop, m, tb.f + 4 * nch, xf,
+                                        (float *)Xs, rp, nullptr, 5, nch, x_ld, ld / 8));
+            spec_zm = 1;
         } else if (use_bf16) {
             const RunPart rp = run_partition_2d(xf.L, (m + 1) / 2, g.ncu, nch);
             LAUNCHCHK(launch_stft_rp(lc(), xd + (size_t)f0 * (size_t)hop, (const float *)win_d, hop, m, tb.f + 4 * nch,
@@ -1355,7 +1371,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                                       1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
         }
         if (use_bf16) {
-            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, m, nb, G, ld));
+            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, m, nb, G, ld, spec_zm));
         } else if (use_fused) {
             LAUNCHCHK(launch_csdm_fused(lc(), Xs, Xt, nch, m, nb, G, ld));
         } else if (use_mfma) {
