@@ -73,14 +73,16 @@ int launch_pairspec(LaunchCtx c, const float *x, const float *win, int hop, int6
 
 int launch_csd_pair(LaunchCtx c, const float *y, int nch, int64_t y_ld, const float *win, int hop, int64_t nframes,
                     const float *trend_y, bool lin, const Xf &xf, const cf *Zx, float *partial, const RunPart &rp) {
+    const int cf_ = (rp.blocks <= 65535 && !getenv("SP_CSD_RUNFAST")) ? 1 : 0;       // channel-fastest block order (grid.y <= 65535)
+    const dim3 grid_ = cf_ ? dim3(nch, rp.blocks) : dim3(rp.blocks, nch);
 #define CP_(NN)                                                                                       \
     case NN:                                                                                          \
-        if (lin) hipLaunchKernelGGL((k_welch_csd_pair<NN, true>), dim3(rp.blocks, nch), dim3(WgCfg<NN>::WG),     \
+        if (lin) hipLaunchKernelGGL((k_welch_csd_pair<NN, true>), grid_, dim3(WgCfg<NN>::WG),         \
                                     WgCfg<NN>::lds_bytes(1), c.stream, y, y_ld, win, hop, nframes, rp.fpg, trend_y, xf.tb, Zx, \
-                                    partial, rp.groups);                                              \
-        else hipLaunchKernelGGL((k_welch_csd_pair<NN, false>), dim3(rp.blocks, nch), dim3(WgCfg<NN>::WG),        \
+                                    partial, rp.groups, cf_);                                         \
+        else hipLaunchKernelGGL((k_welch_csd_pair<NN, false>), grid_, dim3(WgCfg<NN>::WG),            \
                                 WgCfg<NN>::lds_bytes(1), c.stream, y, y_ld, win, hop, nframes, rp.fpg, trend_y, xf.tb, Zx,     \
-                                partial, rp.groups);                                                  \
+                                partial, rp.groups, cf_);                                             \
         break;
     switch (xf.L) {
         CP_(32) CP_(64) CP_(128) CP_(256) CP_(512) CP_(1024) CP_(2048) CP_(4096) CP_(8192)
