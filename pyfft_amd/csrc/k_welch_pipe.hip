@@ -20,9 +20,10 @@
 #define SP_PIPE_ES 1
 #endif
 // SP_PIPE_AHEAD: the front role loads the new samples 1 or 2 frames ahead of use
-// SP_PIPE_SPREAD=1 (with SP_PIPE_AHEAD=2): the front role issues its loads in four groups spread over the period
+// SP_PIPE_SPREAD=1 (with SP_PIPE_AHEAD=2): the front role issues its loads in four groups spread over the period.  Defaults 2 / 1:
+// -2 % per bench step (0.570 against 0.583 ms, three interleaved runs); two frames ahead alone changes nothing
 #ifndef SP_PIPE_SPREAD
-#define SP_PIPE_SPREAD 0
+#define SP_PIPE_SPREAD 1
 #endif
 // SP_PIPE_NT=1: the front role streams the samples with the non-temporal policy
 #ifndef SP_PIPE_NT
@@ -36,7 +37,7 @@
 #define SP_PIPE_PRIO 0
 #endif
 #ifndef SP_PIPE_AHEAD
-#define SP_PIPE_AHEAD 1
+#define SP_PIPE_AHEAD 2
 #endif
 namespace sp {
 
@@ -266,6 +267,10 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             }
         };
         auto issue = [&](cf (&dst)[SHIFT], int64_t q) __attribute__((always_inline)) { issue_part(dst, q, 0, SHIFT); };
+        // two frames ahead + spread loads up to hop = nfft/2; at hop = nfft (16 new slots per frame) a second set of incoming
+        // registers does not fit (56 spills): one frame ahead, one burst
+        constexpr int AHEAD = (SP_PIPE_AHEAD == 2 && SHIFT <= 8) ? 2 : 1;
+        constexpr bool SPREAD = SP_PIPE_SPREAD && AHEAD == 2 && !SP_ABLATE;
         // one period: loads of frame i + AHEAD go out first and are consumed AHEAD periods later (`fill`); `take` holds the
         // new slots of frame i + 1
         auto frame = [&](int64_t i, cf *img, cf (&fill)[SHIFT], cf (&take)[SHIFT]) __attribute__((always_inline)) {
@@ -273,11 +278,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             const unsigned long long ti0_ = __builtin_amdgcn_s_memtime();
             __builtin_amdgcn_sched_barrier(0);
 #endif
-#if SP_PIPE_SPREAD
-            issue_part(fill, i + SP_PIPE_AHEAD, 0, SHIFT / 4);
-#else
-            issue(fill, i + SP_PIPE_AHEAD);
-#endif
+            if constexpr (SPREAD) issue_part(fill, i + AHEAD, 0, SHIFT / 4);
+            else issue(fill, i + AHEAD);
             __builtin_amdgcn_sched_barrier(0);          // keep the loads above the arithmetic (hipcc sank them to the barrier)
 #if SP_PIPE_TIMING
             t_issue += __builtin_amdgcn_s_memtime() - ti0_;
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             cf v[R];
 #pragma unroll
             for (int t = 0; t < R; ++t) v[t] = w[t] * raw[t];
-#if SP_PIPE_SPREAD
+            if constexpr (SPREAD) {
             // the other three quarters of the loads leave behind the store groups of the butterfly: a CU keeps about
             // 24-32 KiB of misses in flight (tools/ubench/stream_mlp.hip) and HBM latency is about one period, so a burst of
             // 16 KiB at the top of a period blocks at issue (350 cycles per period measured) while the same loads spread
@@ -294,17 +296,19 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             {
                 auto store = [&](int k, cf val) __attribute__((always_inline)) {
                     img[F::template phys<0>(tid * 16 + k)] = val;
-                    if (k >= 12 && k < 15) issue_part(fill, i + SP_PIPE_AHEAD, (k - 11) * (SHIFT / 4), (k - 10) * (SHIFT / 4));
+                    if (k >= 12 && k < 15) issue_part(fill, i + AHEAD, (k - 11) * (SHIFT / 4), (k - 10) * (SHIFT / 4));
                 };
                 dft16s_es<false>(v, f.t16[0], store);
             }
-#elif SP_PIPE_ES && !SP_ABLATE
+            } else {
+#if SP_PIPE_ES && !SP_ABLATE
             f.template bfly_scatter<0>(v, img, tid);
 #else
             f.template bfly<0>(v, tid);
             if constexpr (!(SP_ABLATE & 2)) f.template scatter<0>(v, img, tid);
             else asm volatile("" ::"v"(v[0].x), "v"(v[5].y), "v"(v[10].x), "v"(v[15].y));
 #endif
+            }
             __builtin_amdgcn_sched_barrier(0);
             // off the critical path of the period: the stores above drain while these issue
 #pragma unroll
@@ -316,33 +320,33 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             for (int s = 0; s < SHIFT; ++s) raw[KEEP + s] = take[s] - mu;
         };
         int64_t i = 0;
-#if SP_PIPE_AHEAD == 2
-        cf nxa[SHIFT], nxb[SHIFT];
-        issue(nxa, 1);
-        for (; i + 1 < trips; i += 2) {
-            frame(i, imgA, nxb, nxa);
-            PIPE_SYNC();
-            frame(i + 1, imgA + IMG, nxa, nxb);
-            PIPE_SYNC();
+        if constexpr (AHEAD == 2) {
+            cf nxa[SHIFT], nxb[SHIFT];
+            issue(nxa, 1);
+            for (; i + 1 < trips; i += 2) {
+                frame(i, imgA, nxb, nxa);
+                PIPE_SYNC();
+                frame(i + 1, imgA + IMG, nxa, nxb);
+                PIPE_SYNC();
+            }
+            if (i < trips) {
+                frame(i, imgA, nxb, nxa);
+                PIPE_SYNC();
+            }
+        } else {
+            for (; i + 1 < trips; i += 2) {
+                cf nx0[SHIFT], nx1[SHIFT];
+                frame(i, imgA, nx0, nx0);
+                PIPE_SYNC();
+                frame(i + 1, imgA + IMG, nx1, nx1);
+                PIPE_SYNC();
+            }
+            if (i < trips) {
+                cf nx0[SHIFT];
+                frame(i, imgA, nx0, nx0);
+                PIPE_SYNC();
+            }
         }
-        if (i < trips) {
-            frame(i, imgA, nxb, nxa);
-            PIPE_SYNC();
-        }
-#else
-        for (; i + 1 < trips; i += 2) {
-            cf nx0[SHIFT], nx1[SHIFT];
-            frame(i, imgA, nx0, nx0);
-            PIPE_SYNC();
-            frame(i + 1, imgA + IMG, nx1, nx1);
-            PIPE_SYNC();
-        }
-        if (i < trips) {
-            cf nx0[SHIFT];
-            frame(i, imgA, nx0, nx0);
-            PIPE_SYNC();
-        }
-#endif
 #pragma unroll
         for (int d = 0; d < DRAIN; ++d) PIPE_SYNC();
 #pragma unroll
