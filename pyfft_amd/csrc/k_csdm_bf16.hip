@@ -107,12 +107,8 @@ __device__ __forceinline__ bf16x8 neg8(bf16x8 a) {
 #define CB_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
 #endif
 
-// ZM: the rows hold the PACKED pair spectrum instead of the two frames' spectra -- [8 bins Z[k]][their mirrors Z[N-k]] (written by
-// k_welch_pipe mode 5, which needs no mirror exchange for it) -- and every lane forms its own frame's spectrum on the way
-// in: X_2q = (Z + conj Zm)/2, X_2q+1 = (Z - conj Zm)/(2i) (k_stft_rp's split; bins 0 and N/2 are their own mirrors).
-template <bool ZM>
 static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__ Xs, int nch, int64_t npairs, int ld, int ngroups,
-                                                          double *__restrict__ G, int64_t ps, int slices, int atomic, int nyq) {
+                                                          double *__restrict__ G, int64_t ps, int slices, int atomic) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *lds = reinterpret_cast<cf *>(smem_raw);
     const int unit = blockIdx.x;
@@ -175,21 +171,7 @@ static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__
     lstore(0);
     __syncthreads();
     // this lane's elements of a tile: (pair q, channel col / col + 32, bin `wave`, frame `half`)
-    const cf *pa0 = lds + col * CB_P + (ZM ? wave : 2 * wave + half);
-    // ZM: x = c1 z.x + c2 z.y + c1 zm.x + c2 zm.y  +  i (c3 z.y - c3 zm.y + c4 z.x - c4 zm.x) with per-lane constants:
-    // frame 2q (half 0): (1/2, 0, 1/2, 0);  frame 2q+1 (half 1): (0, 1/2, 0, -1/2)
-    const float c1 = half ? 0.f : 0.5f, c2 = half ? 0.5f : 0.f, c3 = c1, c4 = half ? -0.5f : 0.f;
-    const bool selfm = ZM && (k0 + wave == 0 || k0 + wave == nyq);        // wave-uniform
-    auto elem = [&](const cf *p) __attribute__((always_inline)) {
-        if constexpr (ZM) {
-            const cf z = p[0];
-            cf zm = p[CB_BINS];
-            if (selfm) zm = z;
-            return mk(fmaf(c2, zm.y, fmaf(c1, zm.x, fmaf(c2, z.y, c1 * z.x))), fmaf(-c4, zm.x, fmaf(-c3, zm.y, fmaf(c4, z.x, c3 * z.y))));
-        } else {
-            return p[0];
-        }
-    };
+    const cf *pa0 = lds + col * CB_P + 2 * wave + half;
     for (int it = 0; it < ntiles; ++it) {
         const bool more = it + 1 < ntiles;                    // workgroup-uniform
         if (more) gfetch(pbeg + (int64_t)(it + 1) * CB_FP);
@@ -201,8 +183,8 @@ static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__
         cf xe[CB_FP][2];
 #pragma unroll
         for (int q = 0; q < CB_FP; ++q) {
-            xe[q][0] = elem(pa + (q * 64) * CB_P);
-            xe[q][1] = elem(pa + (q * 64 + 32) * CB_P);
+            xe[q][0] = pa[(q * 64) * CB_P];
+            xe[q][1] = pa[(q * 64 + 32) * CB_P];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -268,8 +250,8 @@ static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__
         cf xe[CB_FP][2];
 #pragma unroll
         for (int q = 0; q < CB_FP; ++q) {
-            xe[q][0] = elem(pa + (q * 64) * CB_P);
-            xe[q][1] = elem(pa + (q * 64 + 32) * CB_P);
+            xe[q][0] = pa[(q * 64) * CB_P];
+            xe[q][1] = pa[(q * 64 + 32) * CB_P];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -337,30 +319,46 @@ static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__
 
 // tail bins (those that do not fill a group of 8: the Nyquist bin of every power-of-two nfft) for k_csdm_mfma:
 // Xt[kk][g][c] = Xs[c][g / 2][kfirst + kk][g % 2], zero padded (kk < ntail <= 8)
-// (zm: packed pair spectra; the only tail bin of a power-of-two length is the Nyquist bin, its own mirror: X_2q = Re Z, X_2q+1 = Im Z)
 static __global__ void k_csdm_gather_bins_pi(const cf *__restrict__ Xs, cf *__restrict__ Xt, int nch, int nchp, int64_t m, int64_t mp,
-                                             int64_t npairs, int ld, int kfirst, int ntail, int zm) {
+                                             int64_t npairs, int ld, int kfirst, int ntail) {
     const int64_t g = blockIdx.x;
     for (int e = threadIdx.x; e < ntail * nchp; e += blockDim.x) {
         const int kk = e / nchp, c = e % nchp;
         const bool ok = c < nch && g < m;
-        if (zm) {
-            const cf z = Xs[ok ? ((((g / 2) * (int64_t)(ld / CB_BINS) + kfirst / CB_BINS) * 64 + c) * 16 + (kfirst % CB_BINS) + kk) : 0];
-            Xt[((int64_t)kk * mp + g) * nchp + c] = ok ? mk((g & 1) ? z.y : z.x, 0.f) : mk(0.f, 0.f);
-            continue;
-        }
         const cf v = Xs[ok ? (((((g / 2) * (int64_t)(ld / CB_BINS) + kfirst / CB_BINS) * 64 + c) * CB_BINS + (kfirst % CB_BINS) + kk) * 2 + (g & 1)) : 0];
         Xt[((int64_t)kk * mp + g) * nchp + c] = ok ? v : mk(0.f, 0.f);
     }
 }
 
+// G[k] = (H[k] + conj H[n - k]) / 2, k = 0..n/2, on the blocks the contraction computes (j / 32 >= i / 32): H is the Hermitian
+// contraction of the PACKED pair spectra Z = X_2q + i X_2q+1 over all n bins; the cross terms between the two frames of a pair
+// cancel in the mirror combination (real signals: X[n-k] = conj X[k]), which is therefore taken once, on the sums.
+static __global__ void k_csdm_fold(const double *__restrict__ H, double *__restrict__ G, int nch, int n) {
+    const int64_t per = (int64_t)nch * nch;
+    const int64_t total = (int64_t)(n / 2 + 1) * per;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = e / per, ij = e % per;
+        const int j = (int)(ij % nch), i = (int)(ij / nch);
+        if (j / 32 < i / 32) continue;
+        const int64_t km = (n - k) & (n - 1);
+        const double ar = H[(k * per + ij) * 2], ai = H[(k * per + ij) * 2 + 1];
+        const double br = H[(km * per + ij) * 2], bi = H[(km * per + ij) * 2 + 1];
+        G[e * 2] += 0.5 * (ar + br);
+        G[e * 2 + 1] += 0.5 * (ai - bi);
+    }
+}
+int launch_csdm_fold(LaunchCtx c, const double *H, double *G, int nch, int n) {
+    hipLaunchKernelGGL(k_csdm_fold, dim3(c.ncu * 8), dim3(256), 0, c.stream, H, G, nch, n);
+    return 0;
+}
+
 // Xs: pair-interleaved spectra [nch][npairs][ld][2] of m frames (the second frame of an odd last pair is zero)
-// zm != 0: Xs holds the packed pair spectra [pair][group][channel][2][8] of k_welch_pipe mode 5 (see k_csdm_bf16<ZM>)
-int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld, int zm) {
+// (Xs may also hold PACKED pair spectra with `m` pairs as frames and nb = nfft bins: see k_csdm_fold)
+int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld) {
     if (nch > 64 || ld < nb || (ld % CB_BINS) != 0) return -1;
     const int64_t npairs = (m + 1) / 2;
     const int nchp = 64;
-    const int ngroups = (nb - 1) / CB_BINS;
+    const int ngroups = (nb % CB_BINS) == 0 ? nb / CB_BINS : (nb - 1) / CB_BINS;      // (a whole number of groups: no tail)
     if (ngroups > 0) {
         // frame-pair slices when there are fewer bin groups than CUs; sliced units add atomically
         int slices = (c.ncu + ngroups - 1) / ngroups;
@@ -373,23 +371,17 @@ int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m,
         const size_t lds = 2 * sizeof(cf) * CB_TILE;                              // 68 KiB
         static bool attr_done = false;
         if (!attr_done) {
-            if (hipFuncSetAttribute((const void *)k_csdm_bf16<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-                hipFuncSetAttribute((const void *)k_csdm_bf16<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return -1;
+            if (hipFuncSetAttribute((const void *)k_csdm_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
             attr_done = true;
         }
-        if (zm)
-            hipLaunchKernelGGL(k_csdm_bf16<true>, dim3(ngroups * slices), dim3(512), lds, c.stream, Xs, nch, npairs, ld, ngroups, G, ps,
-                               slices, slices > 1, (nb - 1));
-        else
-            hipLaunchKernelGGL(k_csdm_bf16<false>, dim3(ngroups * slices), dim3(512), lds, c.stream, Xs, nch, npairs, ld, ngroups, G, ps,
-                               slices, slices > 1, (nb - 1));
+        hipLaunchKernelGGL(k_csdm_bf16, dim3(ngroups * slices), dim3(512), lds, c.stream, Xs, nch, npairs, ld, ngroups, G, ps, slices,
+                           slices > 1);
     }
     const int kfirst = CB_BINS * ngroups, ntail = nb - kfirst;
     if (ntail > 0) {
         const int64_t mp = (m + 31) / 32 * 32;
         hipLaunchKernelGGL(k_csdm_gather_bins_pi, dim3((unsigned)mp), dim3(256), 0, c.stream, Xs, Xt_tail, nch, nchp, m, mp, npairs, ld,
-                           kfirst, ntail, zm);
+                           kfirst, ntail);
         if (launch_csdm_mfma(c, Xt_tail, nch, nchp, mp, ntail, G + (int64_t)kfirst * nch * nch * 2)) return -1;
     }
     return 0;

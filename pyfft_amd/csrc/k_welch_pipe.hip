@@ -50,11 +50,13 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
     constexpr int N = 4096;
     constexpr bool RP = MODE >= 3;           // real input, two frames per transform (modes 3: plain, 4: one-pass detrend, 5: spectra)
     constexpr bool ONEPASS = MODE == 1 || MODE == 4, COG = MODE == 2;
-    // mode 5: no accumulation -- the packed pair spectrum Z = X_2q + i X_2q+1 of every frame pair is WRITTEN, for the CSD-matrix
-    // contraction (k_csdm_bf16<ZM>), as Zs[pair][group of 8 bins][channel slot of 64][2][8]: the 8 bins k of a group in the
-    // first half of a 128-byte line, their mirrors Z[N-k] in the second (the reader forms X_2q = (Z + conj Zm)/2 and
-    // X_2q+1 = (Z - conj Zm)/(2i) itself: no mirror exchange here).  blockIdx.y = channel (x_cs samples apart, trend record
-    // 4 y), gpr = bin groups per row.
+    // mode 5: no accumulation -- the packed pair spectrum Z = X_2q + i X_2q+1 of every frame pair is WRITTEN, all N bins, for the
+    // CSD-matrix contraction: Zs[pair of pairs][group of 8 bins][channel slot of 64][8 bins][2 pairs] (k_csdm_bf16's layout with
+    // "frames" = pairs).  The contraction of the PACKED spectra, H[k] = sum Z_i[k] conj Z_j[k], gives the matrix by the mirror
+    // combination G[k] = (H[k] + conj H[N-k]) / 2 taken ONCE on the sums (k_csdm_fold) -- no mirror exchange per transform.  The
+    // back role keeps the spectrum of an even pair for one period and writes it with the next one as 16-byte stores (full
+    // 128-byte lines per 8 lanes).  blockIdx.y = channel (x_cs samples apart, trend record 4 y), gpr = N / 8 bin groups;
+    // a workgroup's run starts at an even pair.
     constexpr bool SPEC = MODE == 5;
     const void *x = SPEC ? (const void *)(reinterpret_cast<const float *>(x_in) + (int64_t)blockIdx.y * x_cs) : x_in;
     float *trend = SPEC ? trend_in + 4 * blockIdx.y : trend_in;
@@ -387,11 +389,9 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
         float acc[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) acc[t] = 0.f;
-        // SPEC: offset (complex elements) of bin k = tid + T t inside a pair's block, (kk / 8) 1024 + 8 h + kk % 8 with kk = k
-        // (h = 0) for k <= N/2 and kk = N - k (h = 1) above: t < 8: zlo + 32768 t; t > 8: zhi - 32768 (t - 8); t = 8: bin N/2 + tid
-        const unsigned zlo = (unsigned)((tid >> 3) * 1024 + (tid & 7));
-        const unsigned zhi = (unsigned)((((N / 2 - tid) >> 3) * 1024) + 8 + ((N / 2 - tid) & 7));
-        const unsigned z8 = tid == 0 ? (unsigned)((N / 16) * 1024) : zhi;
+        // SPEC: offset (16-byte units) of bin k = tid + T t inside a pair-of-pairs block: (k / 8) 512 + k % 8 = zlo + 16384 t
+        const unsigned zlo = (unsigned)((tid >> 3) * 512 + (tid & 7));
+        cf held[SPEC ? R : 1];                 // SPEC: the spectrum of the even pair, waiting for its odd partner
         cf va[R], vb[R];
         // COG (Doppler.cog / cogspec, Doppler.py:43-81): instead of summing |X|^2 over the frames, every frame's moments
         // sum ks |X|^2, sum |X|^2 (signed bin index ks, every bin) are reduced across the wave; a wave keeps the moments of its
@@ -414,14 +414,22 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             if (p >= 4 && p <= trips + 3) {
                 f.template bfly<2>(use, tid);
                 if constexpr (SPEC) {
-                    // pair block base (uniform): pair * gpr * 1024 + channel * 16 complex elements
-                    cf *zb = reinterpret_cast<cf *>(partial) + ((g0 + (p - 4)) * (int64_t)gpr * 1024 + (int64_t)blockIdx.y * 16);
-                    unsigned bl = zlo, bh = zhi;
-                    asm volatile("" : "+v"(bl), "+v"(bh));          // (keeps hipcc from holding sixteen offsets in registers)
+                    const int64_t pr = g0 + (p - 4);                         // global pair index (uniform); runs start even
+                    const bool lone = (pr & 1) == 0 && p == trips + 3;       // a last even pair without a partner
+                    if ((pr & 1) == 0 && !lone) {
 #pragma unroll
-                    for (int t = 0; t < R; ++t) {
-                        const unsigned o = t < 8 ? bl + 32768u * t : (t == 8 ? z8 : bh - 32768u * (t - 8));
-                        st_stream(zb + o, use[t]);
+                        for (int t = 0; t < R; ++t) held[t] = use[t];
+                    } else {
+                        // block base (uniform): (pair / 2) * gpr * 512 + channel * 8, in 16-byte units
+                        float4 *zb = reinterpret_cast<float4 *>(partial) + ((pr >> 1) * (int64_t)gpr * 512 + (int64_t)blockIdx.y * 8);
+                        unsigned bl = zlo;
+                        asm volatile("" : "+v"(bl));                         // (keeps hipcc from holding sixteen offsets in registers)
+#pragma unroll
+                        for (int t = 0; t < R; ++t) {
+                            const float4 q = lone ? make_float4(use[t].x, use[t].y, 0.f, 0.f)
+                                                  : make_float4(held[t].x, held[t].y, use[t].x, use[t].y);
+                            st_stream(zb + (bl + 16384u * t), q);
+                        }
                     }
                 } else if constexpr (COG) {
                     // ks = tid + c_t with c_t = T t - (N in the upper half): sum ks p = tid sum p + sum c_t p

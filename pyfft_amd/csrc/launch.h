@@ -168,7 +168,8 @@ int launch_csdm_gemm(LaunchCtx c, const cf *Xt, int nch, int64_t mc, int nb, dou
 int launch_csdm_finish(LaunchCtx c, double *G, int nch, int nb, double scale, int blk);
 int launch_csdm_transpose_kgc(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int nchp, int64_t m, int64_t mp, int nb);
 int launch_csdm_mfma(LaunchCtx c, const cf *Xt, int nch, int nchp, int64_t mp, int nb, double *G);
-int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld, int zm = 0);
+int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld);
+int launch_csdm_fold(LaunchCtx c, const double *H, double *G, int nch, int n);
 int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld = 0);
 int launch_hilbert_mid(LaunchCtx c, cf *Z, int64_t M, BigTw bt);
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out,

@@ -81,7 +81,7 @@ struct Ctx {
     Scratch in0, in1, out0, work, small, trends, onepass;
     Scratch pend_trend;                       // trend record a pending sp_welch_accum keeps until sp_welch_finish
     Scratch bigA, bigB, bigT, blueA, blueB, longrec;   // long (multi-kernel) paths
-    Scratch cmS, cmT, cmG;                    // CSD matrix: spectra, bin-major spectra, float64 accumulator
+    Scratch cmS, cmT, cmG, cmH;               // CSD matrix: spectra, bin-major spectra, float64 accumulator, packed-spectra sums
     std::map<int64_t, BigTw> bigtw;           // N -> two-level twiddle tables of the multi-pass FFT
     std::map<int64_t, BlueTab> blue_big;      // n -> chirp[n], FFT_L(chirp*) (unscaled) for multi-pass Bluestein
     std::mutex mu;
@@ -765,6 +765,7 @@ void sp_shutdown(void) {
     g.cmS.release();
     g.cmT.release();
     g.cmG.release();
+    g.cmH.release();
     g.bigA.release();
     g.bigB.release();
     g.bigT.release();
@@ -1319,9 +1320,9 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                                     : (use_mfma ? sizeof(cf) * (size_t)nchp * (size_t)mcp * (size_t)nb : sbytes);
     if (g.cmS.ensure(sbytes) || g.cmT.ensure(tbytes)) return -1;
     cf *Xs = (cf *)g.cmS.p, *Xt = (cf *)g.cmT.p;
+    bool fold_pending = false;                            // packed-spectra path used: H (g.cmH) is folded into G at the end
     for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
         const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
-        int spec_zm = 0;
         hipLaunchKernelGGL(k_trend_shift, dim3((nch + 63) / 64), dim3(64), 0, g.stream, tb.f, tb.f + 4 * nch, nch,
                            (double)f0 * (double)hop);
         if (lng) {
@@ -1335,20 +1336,27 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                 LAUNCHCHK(launch_long_stft_out(lc(), S, m, nfft, SP_SIDED_HALF, 1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)ld, 0, ld));
             }
         } else if (use_bf16 && nfft == 4096 && 2 * hop == nfft && detrend != 2 && (m + 1) / 2 >= 32 * (int64_t)((g.ncu + nch - 1) / nch) &&
-                   welch_pipe_wanted(xf, hop, (int64_t)1 << 40) && env_flag("SP_CSDM_PIPESPEC")) {
-            // experiment, off by default (SP_CSDM_PIPESPEC=1): the spectra stage as the pipeline of specialised waves
-            // (k_welch_pipe mode 5) -- it writes the PACKED pair spectra and needs no mirror exchange; the contraction splits them
-            // while loading (k_csdm_bf16<ZM>).  Correct, but 3.9 ms against k_stft_rp's 2.9: a bin and its mirror live in
-            // different threads, so each 128-byte line [8 bins | 8 mirrors] is written in two 64-byte halves by different stores
+                   welch_pipe_wanted(xf, hop, (int64_t)1 << 40) && !env_flag("SP_CSDM_NOPIPESPEC")) {
+            // nfft 4096 at 50 % overlap: the spectra stage is the pipeline of specialised waves (k_welch_pipe mode 5).  It writes
+            // the PACKED pair spectra Z = X_2q + i X_2q+1 (all 4096 bins, two pairs side by side) and needs no mirror exchange;
+            // the contraction runs on them as they are (H[k] = sum Z_i conj Z_j, same work: 4096 bins x pairs instead of 2049 x
+            // frames) and the mirror combination G[k] = (H[k] + conj H[N-k]) / 2 is taken once at the end (k_csdm_fold)
             const int64_t pairs = (m + 1) / 2;
             const int runs = (g.ncu + nch - 1) / nch > 0 ? (g.ncu + nch - 1) / nch : 1;
             RunPart rp;
-            rp.fpg = (pairs + runs - 1) / runs;
+            rp.fpg = ((pairs + runs - 1) / runs + 1) & ~(int64_t)1;               // even: every run starts at an even pair
             rp.blocks = (int)((pairs + rp.fpg - 1) / rp.fpg);
             rp.groups = rp.blocks;
+            const size_t zbytes = (size_t)128 * 64 * 512 * (size_t)((pairs + 1) / 2);
+            const size_t hbytes = sizeof(double) * 2 * (size_t)nfft * (size_t)nch * (size_t)nch;
+            if (g.cmS.ensure(zbytes) || g.cmH.ensure(hbytes)) return -1;
+            Xs = (cf *)g.cmS.p;
+            if (!fold_pending) HIPCHK(hipMemsetAsync(g.cmH.p, 0, hbytes, g.stream));
+            fold_pending = true;
             LAUNCHCHK(launch_welch_pipe(lc(), xd + (size_t)f0 * (size_t)hop, false, (const float *)win_d, hop, m, tb.f + 4 * nch, xf,
-                                        (float *)Xs, rp, nullptr, 5, nch, x_ld, ld / 8));
-            spec_zm = 1;
+                                        (float *)Xs, rp, nullptr, 5, nch, x_ld, nfft / 8));
+            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, pairs, nfft, (double *)g.cmH.p, nfft));
+            continue;
         } else if (use_bf16) {
             const RunPart rp = run_partition_2d(xf.L, (m + 1) / 2, g.ncu, nch);
             LAUNCHCHK(launch_stft_rp(lc(), xd + (size_t)f0 * (size_t)hop, (const float *)win_d, hop, m, tb.f + 4 * nch,
@@ -1371,7 +1379,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                                       1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
         }
         if (use_bf16) {
-            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, m, nb, G, ld, spec_zm));
+            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, m, nb, G, ld));
         } else if (use_fused) {
             LAUNCHCHK(launch_csdm_fused(lc(), Xs, Xt, nch, m, nb, G, ld));
         } else if (use_mfma) {
@@ -1383,6 +1391,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
             LAUNCHCHK(launch_csdm_gemm(lc(), Xt, nch, m, nb, G));
         }
     }
+    if (fold_pending) LAUNCHCHK(launch_csdm_fold(lc(), (const double *)g.cmH.p, G, nch, nfft));
     LAUNCHCHK(launch_csdm_finish(lc(), G, nch, nb, scale / (double)nframes, use_mfma ? 32 : SP_CM_B));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(g_out, G, gbytes, hipMemcpyDeviceToHost, g.stream));

@@ -463,22 +463,28 @@ def test_csd_matrix_bf16_split_is_float32_accurate(E, nch, nfft, hop, nsig):
     assert np.max(np.abs(G - np.conj(np.swapaxes(G, 1, 2)))) <= 1e-6 * peak
 
 
-def test_csd_matrix_pipeline_spectra_option(E):
-    """SP_CSDM_PIPESPEC=1 (off by default, measured slower): nfft 4096 at 50 % overlap with the spectra stage on the pipeline of
-    specialised waves (packed pair spectra, split by the contraction while loading) gives the same matrix"""
+def test_csd_matrix_packed_spectra_path(E):
+    """nfft 4096 at 50 % overlap: the spectra stage runs on the pipeline of specialised waves and writes the PACKED pair
+    spectra; the contraction runs on them and the mirror combination G[k] = (H[k] + conj H[N-k]) / 2 is taken once on the
+    sums.  Against the per-frame spectra path (SP_CSDM_NOPIPESPEC=1) and the oracle; odd frame count (a lone last frame), odd
+    pair count (a lone last pair), fewer than 64 channels"""
     import os
-    rng = np.random.default_rng(77)
-    nch, nfft, hop, M = 64, 4096, 2048, 301
-    nsig = (M - 1) * hop + nfft
-    x = (rng.standard_normal((nch, nsig)) + 0.7 * rng.standard_normal(nsig)[None, :] + 0.1).astype(np.float32)
-    win = O.windows("Hanning", nwins=nfft)
-    G0 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
-    os.environ["SP_CSDM_PIPESPEC"] = "1"
-    try:
+    for nch, M, seed in ((64, 301, 77), (64, 303, 78), (20, 830, 79)):
+        rng = np.random.default_rng(seed)
+        nfft, hop = 4096, 2048
+        nsig = (M - 1) * hop + nfft
+        x = (rng.standard_normal((nch, nsig)) + 0.7 * rng.standard_normal(nsig)[None, :] + 0.1).astype(np.float32)
+        win = O.windows("Hanning", nwins=nfft)
         G1 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
-    finally:
-        del os.environ["SP_CSDM_PIPESPEC"]
-    assert np.max(np.abs(G1 - G0)) <= 3e-6 * np.abs(G0).max()
+        os.environ["SP_CSDM_NOPIPESPEC"] = "1"
+        try:
+            G0 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+        finally:
+            del os.environ["SP_CSDM_NOPIPESPEC"]
+        assert np.max(np.abs(G1 - G0)) <= 3e-6 * np.abs(G0).max(), (nch, M)
+        assert np.max(np.abs(G1 - np.conj(np.swapaxes(G1, 1, 2)))) <= 1e-6 * np.abs(G1).max()
+    ref = O.csd_matrix(x[:3].astype(np.float64), win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+    assert np.max(np.abs(G1[:, :3, :3] - ref)) <= 2e-5 * np.abs(ref).max()
 
 
 def test_welch_csd_real_pair_equals_plain(E):
