@@ -333,25 +333,72 @@ static __global__ void k_csdm_gather_bins_pi(const cf *__restrict__ Xs, cf *__re
 // G[k] = (H[k] + conj H[n - k]) / 2, k = 0..n/2, on the blocks the contraction computes (j / 32 >= i / 32): H is the Hermitian
 // contraction of the PACKED pair spectra Z = X_2q + i X_2q+1 over all n bins; the cross terms between the two frames of a pair
 // cancel in the mirror combination (real signals: X[n-k] = conj X[k]), which is therefore taken once, on the sums.
-static __global__ void k_csdm_fold(const double *__restrict__ H, double *__restrict__ G, int nch, int n) {
+// One workgroup per bin k.  st != null: the one-pass mean correction in the same sweep over G.
+// The spectra were detrended by the estimates mu0_i; with d_i = mean_i - mu0_i (real), W = FFT(window), B_i = sum_g X_i,g:
+//   sum_g (X_i - d_i W) conj(X_j - d_j W) = G_ij - d_j conj(W) B_i - d_i W conj(B_j) + M d_i d_j |W|^2
+// st[ch] = state of k_op_finish<EXPORT>: B at [n .. 3n), the channel's plain sample sum at 5n + 3; nmean samples per channel
+static __global__ __launch_bounds__(256) void k_csdm_fold(const double *__restrict__ H, double *__restrict__ G, int nch, int n,
+                                                          const double *__restrict__ st, const cf *__restrict__ Wf,
+                                                          const float *__restrict__ trend, int64_t nmean, int64_t M) {
+    __shared__ double sd[64], sbr[64], sbi[64];
     const int64_t per = (int64_t)nch * nch;
-    const int64_t total = (int64_t)(n / 2 + 1) * per;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t k = e / per, ij = e % per;
-        const int j = (int)(ij % nch), i = (int)(ij / nch);
+    const int k = blockIdx.x;
+    const int64_t km = (n - k) & (n - 1);
+    double wr = 0.0, wi = 0.0;
+    if (st) {
+        const int64_t ss = (int64_t)5 * n + 8;
+        if ((int)threadIdx.x < nch) {
+            const int c = threadIdx.x;
+            sd[c] = st[c * ss + 5 * n + 3] / (double)nmean - (double)trend[4 * c];
+            sbr[c] = st[c * ss + n + 2 * k];
+            sbi[c] = st[c * ss + n + 2 * k + 1];
+        }
+        wr = Wf[k].x;
+        wi = Wf[k].y;
+        __syncthreads();
+    }
+    const double mw = (double)M * (wr * wr + wi * wi);
+    for (int ij = threadIdx.x; ij < (int)per; ij += 256) {
+        const int j = ij % nch, i = ij / nch;
         if (j / 32 < i / 32) continue;
-        const int64_t km = (n - k) & (n - 1);
-        const double ar = H[(k * per + ij) * 2], ai = H[(k * per + ij) * 2 + 1];
-        const double br = H[(km * per + ij) * 2], bi = H[(km * per + ij) * 2 + 1];
-        G[e * 2] += 0.5 * (ar + br);
-        G[e * 2 + 1] += 0.5 * (ai - bi);
+        const double2 a = reinterpret_cast<const double2 *>(H)[k * per + ij];
+        const double2 b = reinterpret_cast<const double2 *>(H)[km * per + ij];
+        double2 gv = reinterpret_cast<double2 *>(G)[k * per + ij];
+        gv.x += 0.5 * (a.x + b.x);
+        gv.y += 0.5 * (a.y - b.y);
+        if (st) {
+            const double di = sd[i], dj = sd[j];
+            gv.x += -dj * (wr * sbr[i] + wi * sbi[i]) - di * (wr * sbr[j] + wi * sbi[j]) + mw * di * dj;
+            gv.y += -dj * (wr * sbi[i] - wi * sbr[i]) - di * (wi * sbr[j] - wr * sbi[j]);
+        }
+        reinterpret_cast<double2 *>(G)[k * per + ij] = gv;
     }
 }
-int launch_csdm_fold(LaunchCtx c, const double *H, double *G, int nch, int n) {
-    hipLaunchKernelGGL(k_csdm_fold, dim3(c.ncu * 8), dim3(256), 0, c.stream, H, G, nch, n);
+int launch_csdm_fold(LaunchCtx c, const double *H, double *G, int nch, int n, const double *st, const cf *Wf, const float *trend,
+                     int64_t nmean, int64_t M) {
+    if (nch > 64) return -1;
+    hipLaunchKernelGGL(k_csdm_fold, dim3(n / 2 + 1), dim3(256), 0, c.stream, H, G, nch, n, st, Wf, trend, nmean, M);
     return 0;
 }
 
+// ---- one-pass channel means for the packed-spectra path ------------------------------------------------------------------
+// Sl[ch][2j], Sl[ch][2j+1] = sum over the runs of the front role's block sums spartial[ch][run][j] (float64, fixed order)
+static __global__ void k_cm_blocksums(const cf *__restrict__ spartial, int runs, int hop, double *__restrict__ Sl) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
+    if (j >= hop) return;
+    double a = 0.0, b = 0.0;
+    for (int r = 0; r < runs; ++r) {
+        const cf v = spartial[((int64_t)ch * runs + r) * hop + j];
+        a += (double)v.x;
+        b += (double)v.y;
+    }
+    Sl[(int64_t)ch * 2 * hop + 2 * j] = a;
+    Sl[(int64_t)ch * 2 * hop + 2 * j + 1] = b;
+}
+int launch_cm_blocksums(LaunchCtx c, const cf *spartial, int nch, int runs, int hop, double *Sl) {
+    hipLaunchKernelGGL(k_cm_blocksums, dim3((hop + 255) / 256, nch), dim3(256), 0, c.stream, spartial, runs, hop, Sl);
+    return 0;
+}
 // Xs: pair-interleaved spectra [nch][npairs][ld][2] of m frames (the second frame of an odd last pair is zero)
 // (Xs may also hold PACKED pair spectra with `m` pairs as frames and nb = nfft bins: see k_csdm_fold)
 int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld) {

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
                                                      float *__restrict__ partial, cf *__restrict__ spartial, int64_t x_cs, int gpr) {
     constexpr int N = 4096;
     constexpr bool RP = MODE >= 3;           // real input, two frames per transform (modes 3: plain, 4: one-pass detrend, 5: spectra)
-    constexpr bool ONEPASS = MODE == 1 || MODE == 4, COG = MODE == 2;
+    constexpr bool ONEPASS = MODE == 1 || MODE == 4 || MODE == 7, COG = MODE == 2;          // (7: mode 5 with the one-pass block sums)
     // mode 5: no accumulation -- the packed pair spectrum Z = X_2q + i X_2q+1 of every frame pair is WRITTEN, all N bins, for the
     // CSD-matrix contraction: Zs[pair of pairs][group of 8 bins][channel slot of 64][8 bins][2 pairs] (k_csdm_bf16's layout with
     // "frames" = pairs).  The contraction of the PACKED spectra, H[k] = sum Z_i[k] conj Z_j[k], gives the matrix by the mirror
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
     // back role keeps the spectrum of an even pair for one period and writes it with the next one as 16-byte stores (full
     // 128-byte lines per 8 lanes).  blockIdx.y = channel (x_cs samples apart, trend record 4 y), gpr = N / 8 bin groups;
     // a workgroup's run starts at an even pair.
-    constexpr bool SPEC = MODE == 5;
+    constexpr bool SPEC = MODE == 5 || MODE == 7;
     const void *x = SPEC ? (const void *)(reinterpret_cast<const float *>(x_in) + (int64_t)blockIdx.y * x_cs) : x_in;
     float *trend = SPEC ? trend_in + 4 * blockIdx.y : trend_in;
     static_assert(!RP || (!CPLX && SHIFT == 8), "the real-pair form is for real input at hop = nfft / 2");
@@ -78,30 +78,38 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
     if constexpr (ONEPASS) {
         const int64_t span = (nframes - 1) * (int64_t)hop + N;
         const int64_t pitch = span / 16;
+        // SPEC (many channels, cross terms): 16 runs of 3072 samples read by all twelve waves.  The spectra carry d W with
+        // d = mean - mu0 in the bins of the window's main lobe, coherently in every frame and channel, until the epilogue
+        // removes it again: the float32 accumulators of the contraction lose what that sum exceeds the signal by, so the
+        // estimate has to be good (d ~ sigma / 220; with 4096 samples the full-size Hermitian check saw 7e-6 of the peak)
+        constexpr int NU = SPEC ? 4 : 1, NTH = SPEC ? 3 * T : T, NWV = SPEC ? 12 : 4;
+        const int lt = SPEC ? (int)threadIdx.x : tid;
         float sx = 0.f, sy = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int64_t i = pitch * r + (int64_t)tid;
-            i = i < span ? i : span - 1;
-            const cf v = load_sample(x, i, CPLX);
-            sx += v.x;
-            sy += v.y;
-        }
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                int64_t i = pitch * r + (int64_t)(lt + NTH * u);
+                i = i < span ? i : span - 1;
+                const cf v = load_sample(x, i, CPLX);
+                sx += v.x;
+                sy += v.y;
+            }
         sx = wave_sum64(sx);
         sy = wave_sum64(sy);
         float *red = reinterpret_cast<float *>(smem);
-        if (role == 0 && (tid & 63) == 0) {
-            red[2 * (tid >> 6)] = sx;
-            red[2 * (tid >> 6) + 1] = sy;
+        if ((SPEC || role == 0) && (tid & 63) == 0) {
+            red[2 * (lt >> 6)] = sx;
+            red[2 * (lt >> 6) + 1] = sy;
         }
         __syncthreads();
         double tx = 0.0, ty = 0.0;
 #pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
+        for (int wv = 0; wv < NWV; ++wv) {
             tx += (double)red[2 * wv];
             ty += (double)red[2 * wv + 1];
         }
-        mu = mk((float)(tx / (16.0 * T)), (float)(ty / (16.0 * T)));
+        mu = mk((float)(tx / (16.0 * NTH * NU)), (float)(ty / (16.0 * NTH * NU)));
         __syncthreads();
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             trend[0] = mu.x;
@@ -224,7 +232,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
         for (int d = 0; d < DRAIN; ++d) PIPE_SYNC();
         if constexpr (ONEPASS) {
 #pragma unroll
-            for (int s = 0; s < SHIFT; ++s) spartial[gid * hop + tid + T * s] = mk(sacc[s], 0.f);
+            for (int s = 0; s < SHIFT; ++s)
+                spartial[((SPEC ? (int64_t)blockIdx.y * gridDim.x : 0) + gid) * hop + tid + T * s] = mk(sacc[s], 0.f);   // SPEC: [channel][run][hop]
         }
     } else if (role == 0) {
         if constexpr (SP_PIPE_PRIO) __builtin_amdgcn_s_setprio((SP_PIPE_PRIO / 100) % 10);
@@ -512,7 +521,7 @@ int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, i
     if (shift == 8) PIPE_(CP, 8, OP) else if (shift == 4) PIPE_(CP, 4, OP) else PIPE_(CP, 16, OP)
     if (mode == 5) {
         if (cplx || shift != 8 || nch < 1 || gpr < 1) return -1;
-        PIPE_(false, 8, 5)
+        if (spartial) PIPE_(false, 8, 7) else PIPE_(false, 8, 5)
     } else if (mode == 3) {
         if (cplx || shift != 8) return -1;
         if (spartial) PIPE_(false, 8, 4) else PIPE_(false, 8, 3)

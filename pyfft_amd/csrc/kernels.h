@@ -1100,10 +1100,17 @@ static __global__ __launch_bounds__(WgCfg<N>::WG) void k_op_finish(const void *_
                                                                     const double *__restrict__ dlt_local,
                                                                     const double *__restrict__ mean_in, int H, int r,
                                                                     int64_t M, int64_t nmean, int sided, double scale,
-                                                                    XfTables tb, double *__restrict__ out, int sym) {
+                                                                    XfTables tb, double *__restrict__ out, int sym,
+                                                                    int64_t x_cs = 0, int64_t sl_cs = 0, int64_t out_cs = 0) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
+    // one workgroup per signal: blockIdx.x selects the channel of a multi-channel call (strides in samples / doubles; all zero
+    // for the single-signal callers, whose grid is one workgroup)
+    x = reinterpret_cast<const char *>(x) + (int64_t)blockIdx.x * x_cs * (CPLX ? 8 : 4);
+    trend += x_cs ? 4 * blockIdx.x : 0;
+    Sl += (int64_t)blockIdx.x * sl_cs;
+    out += (int64_t)blockIdx.x * out_cs;
     const cf mu = mk(trend[0], trend[1]);
     // this single workgroup is one chain of memory round trips: everything that does not depend on a computed value
     // (window, raw sums, FFT(window)) is fetched up front, together with the twiddle tables of the prologue

@@ -81,7 +81,7 @@ struct Ctx {
     Scratch in0, in1, out0, work, small, trends, onepass;
     Scratch pend_trend;                       // trend record a pending sp_welch_accum keeps until sp_welch_finish
     Scratch bigA, bigB, bigT, blueA, blueB, longrec;   // long (multi-kernel) paths
-    Scratch cmS, cmT, cmG, cmH;               // CSD matrix: spectra, bin-major spectra, float64 accumulator, packed-spectra sums
+    Scratch cmS, cmT, cmG, cmH, cmO;               // CSD matrix: spectra, bin-major spectra, float64 accumulator, packed-spectra sums, one-pass means state
     std::map<int64_t, BigTw> bigtw;           // N -> two-level twiddle tables of the multi-pass FFT
     std::map<int64_t, BlueTab> blue_big;      // n -> chirp[n], FFT_L(chirp*) (unscaled) for multi-pass Bluestein
     std::mutex mu;
@@ -766,6 +766,7 @@ void sp_shutdown(void) {
     g.cmT.release();
     g.cmG.release();
     g.cmH.release();
+    g.cmO.release();
     g.bigA.release();
     g.bigB.release();
     g.bigT.release();
@@ -1262,21 +1263,6 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
     TrendBuf tb;
     if (get_trendbuf(2 * nch, &tb)) return -1;           // second half: trends re-based to the current frame chunk
-    if (means_host) {
-        // caller-supplied constants (detrend == SP_DETREND_CONST semantics)
-        double *md = tb.d;
-        HIPCHK(hipMemcpyAsync(md, means_host, sizeof(double) * (size_t)nch, hipMemcpyHostToDevice, g.stream));
-        hipLaunchKernelGGL(k_set_trends, dim3((nch + 63) / 64), dim3(64), 0, g.stream, md, tb.f, nch);
-    } else if (detrend == 0) {
-        HIPCHK(hipMemsetAsync(tb.f, 0, sizeof(float) * 4 * (size_t)nch, g.stream));
-    } else if (nch <= 512) {
-        double *scr = moments_scratch();                 // all channels in one launch
-        if (!scr) return -1;
-        LAUNCHCHK(launch_moments(lc(), xd, false, nsig, detrend, scr, tb.d, tb.f, nch, x_ld));
-    } else {
-        for (int c = 0; c < nch; ++c)
-            if (set_trend(tb, c, xd + (size_t)x_ld * (size_t)c, false, nsig, detrend, 0, 0)) return -1;
-    }
     const size_t gbytes = sizeof(double) * 2 * (size_t)nb * (size_t)nch * (size_t)nch;
     double *G = g_out;
     if (!mem) {
@@ -1320,6 +1306,34 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                                     : (use_mfma ? sizeof(cf) * (size_t)nchp * (size_t)mcp * (size_t)nb : sbytes);
     if (g.cmS.ensure(sbytes) || g.cmT.ensure(tbytes)) return -1;
     cf *Xs = (cf *)g.cmS.p, *Xt = (cf *)g.cmT.p;
+    // nfft 4096 at 50 % overlap: spectra by the pipeline of specialised waves (see below); m = frames of a chunk
+    auto pipe_spec = [&](int64_t m) {
+        return use_bf16 && nfft == 4096 && 2 * hop == nfft && detrend != 2 && (m + 1) / 2 >= 32 * (int64_t)((g.ncu + nch - 1) / nch) &&
+               welch_pipe_wanted(xf, hop, (int64_t)1 << 40) && !env_flag("SP_CSDM_NOPIPESPEC");
+    };
+    // mean detrend in ONE pass over the signals (single chunk): the spectra stage subtracts an estimate mu0 of every channel's
+    // mean and leaves its block sums; the exact means and B_i = sum_g X_i,g follow from them (k_op_finish per channel) and the
+    // matrix is corrected at the end (k_cm_correct).  Saves the separate pass over all samples for the means
+    const bool cm_onepass = detrend == 1 && !means_host && nframes <= mc && pipe_spec(nframes) && !env_flag("SP_CSDM_TWOPASS");
+    if (cm_onepass) {
+        HIPCHK(hipMemsetAsync(tb.f, 0, sizeof(float) * 4 * (size_t)nch, g.stream));   // (the spectra stage estimates and publishes mu0)
+    } else if (means_host) {
+        // caller-supplied constants (detrend == SP_DETREND_CONST semantics)
+        double *md = tb.d;
+        HIPCHK(hipMemcpyAsync(md, means_host, sizeof(double) * (size_t)nch, hipMemcpyHostToDevice, g.stream));
+        hipLaunchKernelGGL(k_set_trends, dim3((nch + 63) / 64), dim3(64), 0, g.stream, md, tb.f, nch);
+    } else if (detrend == 0) {
+        HIPCHK(hipMemsetAsync(tb.f, 0, sizeof(float) * 4 * (size_t)nch, g.stream));
+    } else if (nch <= 512) {
+        double *scr = moments_scratch();                 // all channels in one launch
+        if (!scr) return -1;
+        LAUNCHCHK(launch_moments(lc(), xd, false, nsig, detrend, scr, tb.d, tb.f, nch, x_ld));
+    } else {
+        for (int c = 0; c < nch; ++c)
+            if (set_trend(tb, c, xd + (size_t)x_ld * (size_t)c, false, nsig, detrend, 0, 0)) return -1;
+    }
+    size_t op_sp = 0, op_sl = 0;
+    int op_runs = 0;
     bool fold_pending = false;                            // packed-spectra path used: H (g.cmH) is folded into G at the end
     for (int64_t f0 = 0; f0 < nframes; f0 += mc) {
         const int64_t m = nframes - f0 < mc ? nframes - f0 : mc;
@@ -1335,8 +1349,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                     return -1;
                 LAUNCHCHK(launch_long_stft_out(lc(), S, m, nfft, SP_SIDED_HALF, 1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)ld, 0, ld));
             }
-        } else if (use_bf16 && nfft == 4096 && 2 * hop == nfft && detrend != 2 && (m + 1) / 2 >= 32 * (int64_t)((g.ncu + nch - 1) / nch) &&
-                   welch_pipe_wanted(xf, hop, (int64_t)1 << 40) && !env_flag("SP_CSDM_NOPIPESPEC")) {
+        } else if (pipe_spec(m)) {
             // nfft 4096 at 50 % overlap: the spectra stage is the pipeline of specialised waves (k_welch_pipe mode 5).  It writes
             // the PACKED pair spectra Z = X_2q + i X_2q+1 (all 4096 bins, two pairs side by side) and needs no mirror exchange;
             // the contraction runs on them as they are (H[k] = sum Z_i conj Z_j, same work: 4096 bins x pairs instead of 2049 x
@@ -1353,8 +1366,17 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
             Xs = (cf *)g.cmS.p;
             if (!fold_pending) HIPCHK(hipMemsetAsync(g.cmH.p, 0, hbytes, g.stream));
             fold_pending = true;
+            cf *spartial = nullptr;
+            if (cm_onepass) {
+                // [channel][run][hop] block sums, then per channel Sl (2 hop doubles) and the finish state (5 nfft + 8 doubles)
+                op_sp = sizeof(cf) * (size_t)nch * (size_t)rp.blocks * (size_t)hop;
+                op_sl = sizeof(double) * 2 * (size_t)hop * (size_t)nch;
+                if (g.cmO.ensure(op_sp + op_sl + sizeof(double) * (size_t)(5 * nfft + 8) * (size_t)nch)) return -1;
+                spartial = (cf *)g.cmO.p;
+                op_runs = rp.blocks;
+            }
             LAUNCHCHK(launch_welch_pipe(lc(), xd + (size_t)f0 * (size_t)hop, false, (const float *)win_d, hop, m, tb.f + 4 * nch, xf,
-                                        (float *)Xs, rp, nullptr, 5, nch, x_ld, nfft / 8));
+                                        (float *)Xs, rp, spartial, 5, nch, x_ld, nfft / 8));
             LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, pairs, nfft, (double *)g.cmH.p, nfft));
             continue;
         } else if (use_bf16) {
@@ -1391,7 +1413,17 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
             LAUNCHCHK(launch_csdm_gemm(lc(), Xt, nch, m, nb, G));
         }
     }
-    if (fold_pending) LAUNCHCHK(launch_csdm_fold(lc(), (const double *)g.cmH.p, G, nch, nfft));
+    if (cm_onepass) {
+        void *Wf_d;
+        if (get_window_spectrum(win, nfft, xf, &Wf_d)) return -1;
+        double *Sl = (double *)((char *)g.cmO.p + op_sp), *st = (double *)((char *)g.cmO.p + op_sp + op_sl);
+        LAUNCHCHK(launch_cm_blocksums(lc(), (const cf *)g.cmO.p, nch, op_runs, hop, Sl));
+        LAUNCHCHK(launch_op_finish_channels(lc(), xd, x_ld, nch, tb.f + 4 * nch, (const float *)win_d, Sl, (const cf *)Wf_d, hop,
+                                            nframes, nsig, xf, st));
+        LAUNCHCHK(launch_csdm_fold(lc(), (const double *)g.cmH.p, G, nch, nfft, st, (const cf *)Wf_d, tb.f + 4 * nch, nsig, nframes));
+    } else if (fold_pending) {
+        LAUNCHCHK(launch_csdm_fold(lc(), (const double *)g.cmH.p, G, nch, nfft));
+    }
     LAUNCHCHK(launch_csdm_finish(lc(), G, nch, nb, scale / (double)nframes, use_mfma ? 32 : SP_CM_B));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(g_out, G, gbytes, hipMemcpyDeviceToHost, g.stream));

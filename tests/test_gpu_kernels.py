@@ -469,11 +469,14 @@ def test_csd_matrix_packed_spectra_path(E):
     sums.  Against the per-frame spectra path (SP_CSDM_NOPIPESPEC=1) and the oracle; odd frame count (a lone last frame), odd
     pair count (a lone last pair), fewer than 64 channels"""
     import os
-    for nch, M, seed in ((64, 301, 77), (64, 303, 78), (20, 830, 79)):
+    # (tail: samples after the last frame, which count for the mean; dc: per-channel offsets, so that the one-pass mean
+    # detrend's correction terms are far above the comparison threshold)
+    for nch, M, seed, tail, dc in ((64, 301, 77, 0, 0.1), (64, 303, 78, 777, 3.0), (20, 830, 79, 5000, -2.0)):
         rng = np.random.default_rng(seed)
         nfft, hop = 4096, 2048
-        nsig = (M - 1) * hop + nfft
-        x = (rng.standard_normal((nch, nsig)) + 0.7 * rng.standard_normal(nsig)[None, :] + 0.1).astype(np.float32)
+        nsig = (M - 1) * hop + nfft + tail
+        x = (rng.standard_normal((nch, nsig)) + 0.7 * rng.standard_normal(nsig)[None, :]
+             + dc * (1 + np.arange(nch))[:, None] / nch).astype(np.float32)
         win = O.windows("Hanning", nwins=nfft)
         G1 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
         os.environ["SP_CSDM_NOPIPESPEC"] = "1"
@@ -481,8 +484,22 @@ def test_csd_matrix_packed_spectra_path(E):
             G0 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
         finally:
             del os.environ["SP_CSDM_NOPIPESPEC"]
+        os.environ["SP_CSDM_TWOPASS"] = "1"           # packed spectra, means by the separate pass
+        try:
+            G2 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+        finally:
+            del os.environ["SP_CSDM_TWOPASS"]
         assert np.max(np.abs(G1 - G0)) <= 3e-6 * np.abs(G0).max(), (nch, M)
+        assert np.max(np.abs(G2 - G0)) <= 3e-6 * np.abs(G0).max(), (nch, M)
         assert np.max(np.abs(G1 - np.conj(np.swapaxes(G1, 1, 2)))) <= 1e-6 * np.abs(G1).max()
+        # no detrend and caller-supplied means take the plain packed path
+        Gn = E.csd_matrix(x, win, hop, M, detrend=False, scale=1.0)
+        os.environ["SP_CSDM_NOPIPESPEC"] = "1"
+        try:
+            Gn0 = E.csd_matrix(x, win, hop, M, detrend=False, scale=1.0)
+        finally:
+            del os.environ["SP_CSDM_NOPIPESPEC"]
+        assert np.max(np.abs(Gn - Gn0)) <= 3e-6 * np.abs(Gn0).max(), (nch, M)
     ref = O.csd_matrix(x[:3].astype(np.float64), win, nfft, hop, M, 1.0) * np.sum(win ** 2)
     assert np.max(np.abs(G1[:, :3, :3] - ref)) <= 2e-5 * np.abs(ref).max()
 
