@@ -107,6 +107,14 @@ __device__ __forceinline__ bf16x8 neg8(bf16x8 a) {
 #define CB_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0)
 #endif
 
+// FORM 4 (long records: csd_matrix_impl selects it from 1024 frame pairs on; SP_CSDM_SPLIT3=1 / SP_CSDM_SPLIT2=1 force a form): TWO pieces x ~ h + m (m rounded to nearest: 16 significant bits, residual <= 2^-16 |x|,
+// zero mean) and the four products h h, h m, m h, m m: A = [h h | m m], B = [h m | h m] -- a part is 2 dwords, an element of one
+// frame exactly one operand [re | im], so the Hermitian 64 x 64 update of a frame pair is 4 MFMAs + 1 for the two diagonal
+// blocks' imaginary parts (two pairs share those): 10 per two pairs instead of 16.  The operands carry 16 bits instead of
+// 24: the products' errors (rms 2^-17 / sqrt 3 each) average out over the frames but not for spectra that repeat exactly
+// from frame to frame (measured there: 7e-7 of the peak against 3e-7, tools/split2_ab.py), hence only for long records where
+// the float32 accumulation is the larger error anyway.
+template <int FORM>
 static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__ Xs, int nch, int64_t npairs, int ld, int ngroups,
                                                           double *__restrict__ G, int64_t ps, int slices, int atomic) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -176,6 +184,49 @@ static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__
         const bool more = it + 1 < ntiles;                    // workgroup-uniform
         if (more) gfetch(pbeg + (int64_t)(it + 1) * CB_FP);
         const cf *pa = pa0 + (it & 1) * CB_TILE;
+        if constexpr (FORM == 4) {
+            cf xe[CB_FP][2];
+#pragma unroll
+            for (int q = 0; q < CB_FP; ++q) {
+                xe[q][0] = pa[(q * 64) * CB_P];
+                xe[q][1] = pa[(q * 64 + 32) * CB_P];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pp = 0; pp < CB_FP / 2; ++pp) {
+                unsigned A[2][2][2][2], B[2][2][2];              // [pair][channel][re/im]: A dwords (h h)(m m), B dword (h m)
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+#pragma unroll
+                        for (int part = 0; part < 2; ++part) {
+                            const float x = part ? xe[2 * pp + f][c].y : xe[2 * pp + f][c].x;
+                            const unsigned h = __float_as_uint(x);
+                            const unsigned m = __float_as_uint(x - __uint_as_float(h & 0xffff0000u)) + 0x8000u;   // (the pack truncates)
+                            A[f][c][part][0] = pk(h, h);
+                            A[f][c][part][1] = pk(m, m);
+                            B[f][c][part] = pk(h, m);
+                        }
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const bf16x8 ar0 = op4(A[f][0][0][0], A[f][0][0][1], A[f][0][1][0], A[f][0][1][1]);
+                    const bf16x8 ar1 = op4(A[f][1][0][0], A[f][1][0][1], A[f][1][1][0], A[f][1][1][1]);
+                    const bf16x8 b0 = op4(B[f][0][0], B[f][0][0], B[f][0][1], B[f][0][1]);
+                    const bf16x8 b1 = op4(B[f][1][0], B[f][1][0], B[f][1][1], B[f][1][1]);
+                    const bf16x8 ai0 = op4(A[f][0][1][0], A[f][0][1][1], A[f][0][0][0] ^ 0x80008000u, A[f][0][0][1] ^ 0x80008000u);   // [i | -r]
+                    CB_MFMA(accR[0], ar0, b0);
+                    CB_MFMA(accR[1], ar0, b1);
+                    CB_MFMA(accR[2], ar1, b1);
+                    CB_MFMA(accI[1], ai0, b1);
+                }
+                // diagonal blocks: P = Xi Xr^T, the two pairs side by side on the K axis
+                CB_MFMA(accI[0], op4(A[0][0][1][0], A[0][0][1][1], A[1][0][1][0], A[1][0][1][1]),
+                        op4(B[0][0][0], B[0][0][0], B[1][0][0], B[1][0][0]));
+                CB_MFMA(accI[2], op4(A[0][1][1][0], A[0][1][1][1], A[1][1][1][0], A[1][1][1][1]),
+                        op4(B[0][1][0], B[0][1][0], B[1][1][0], B[1][1][0]));
+            }
+        } else {
 #if CB_FORM == 6
         // six products per part ((h|h)(h|m) (m|h)(m|m) (h|l)(l|h): everything down to 2^-16 and the two largest 2^-24 terms) in
         // 3-dword groups; a lane's two frames of a pair of pairs make 12 dwords = three MFMA operands per block: 16 MFMAs per
@@ -273,11 +324,12 @@ static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__
             CB_MFMA(accI[2], x1.ia, x1.rb);
         }
 #endif
+        }
 #if CB_INTERLEAVE
         // ask the scheduler for MFMA / VALU interleaving: the operand preparation of the later K-slots runs in the shadow
         // of the earlier MFMAs (an MFMA holds the SIMD's issue for 8 of its 32 cycles)
 #pragma unroll
-        for (int i = 0; i < (CB_FORM == 6 ? 8 : 10) * CB_FP; ++i) {
+        for (int i = 0; i < (FORM == 4 ? 5 : CB_FORM == 6 ? 8 : 10) * CB_FP; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x002, CB_INTERLEAVE, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
@@ -401,7 +453,7 @@ int launch_cm_blocksums(LaunchCtx c, const cf *spartial, int nch, int runs, int 
 }
 // Xs: pair-interleaved spectra [nch][npairs][ld][2] of m frames (the second frame of an odd last pair is zero)
 // (Xs may also hold PACKED pair spectra with `m` pairs as frames and nb = nfft bins: see k_csdm_fold)
-int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld) {
+int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld, int two_pieces) {
     if (nch > 64 || ld < nb || (ld % CB_BINS) != 0) return -1;
     const int64_t npairs = (m + 1) / 2;
     const int nchp = 64;
@@ -418,11 +470,17 @@ int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m,
         const size_t lds = 2 * sizeof(cf) * CB_TILE;                              // 68 KiB
         static bool attr_done = false;
         if (!attr_done) {
-            if (hipFuncSetAttribute((const void *)k_csdm_bf16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+            if (hipFuncSetAttribute((const void *)k_csdm_bf16<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                hipFuncSetAttribute((const void *)k_csdm_bf16<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return -1;
             attr_done = true;
         }
-        hipLaunchKernelGGL(k_csdm_bf16, dim3(ngroups * slices), dim3(512), lds, c.stream, Xs, nch, npairs, ld, ngroups, G, ps, slices,
-                           slices > 1);
+        if (two_pieces)
+            hipLaunchKernelGGL(k_csdm_bf16<4>, dim3(ngroups * slices), dim3(512), lds, c.stream, Xs, nch, npairs, ld, ngroups, G, ps,
+                               slices, slices > 1);
+        else
+            hipLaunchKernelGGL(k_csdm_bf16<0>, dim3(ngroups * slices), dim3(512), lds, c.stream, Xs, nch, npairs, ld, ngroups, G, ps,
+                               slices, slices > 1);
     }
     const int kfirst = CB_BINS * ngroups, ntail = nb - kfirst;
     if (ntail > 0) {

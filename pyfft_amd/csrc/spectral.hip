@@ -1298,6 +1298,11 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     const bool rp_stft = !lng && !xf.blue && xf.L >= 32 && nch <= 65535;
     // bf16-split contraction (k_csdm_bf16.hip): needs the pair-interleaved spectra the real-pair STFT kernel can write
     const bool use_bf16 = use_fused && rp_stft && !env_flag("SP_CSDM_FP32");
+    // two bf16 pieces per operand (16 bits, k_csdm_bf16<4>: 10 MFMAs per two frame pairs instead of 16) from 1024 frame pairs
+    // on: there the float32 accumulation bounds the accuracy of both forms alike (1.6e-6 of the peak at 2049 frames against
+    // the float64 oracle, tools/split2_ab.py) and the operand rounding (rms 2^-17/sqrt 3 per value, zero mean) averages to
+    // <= 2e-7.  SP_CSDM_SPLIT3=1: three pieces always; SP_CSDM_SPLIT2=1: two pieces always
+    const int split2 = env_flag("SP_CSDM_SPLIT2") ? 1 : (env_flag("SP_CSDM_SPLIT3") ? 0 : ((nframes + 1) / 2 >= 1024 ? 1 : 0));
     const int ld = use_bf16 ? (nb + 7) / 8 * 8
                             : ((use_fused && (rp_stft || lng) && !env_flag("SP_CSDM_NOPAD")) ? (nb + 15) / 16 * 16 : nb);
     const size_t sbytes = use_bf16 ? sizeof(cf) * 2 * (size_t)64 * (size_t)((mc + 1) / 2) * (size_t)ld       // 64 channel slots
@@ -1377,7 +1382,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
             }
             LAUNCHCHK(launch_welch_pipe(lc(), xd + (size_t)f0 * (size_t)hop, false, (const float *)win_d, hop, m, tb.f + 4 * nch, xf,
                                         (float *)Xs, rp, spartial, 5, nch, x_ld, nfft / 8));
-            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, pairs, nfft, (double *)g.cmH.p, nfft));
+            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, pairs, nfft, (double *)g.cmH.p, nfft, split2));
             continue;
         } else if (use_bf16) {
             const RunPart rp = run_partition_2d(xf.L, (m + 1) / 2, g.ncu, nch);
@@ -1401,7 +1406,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                                       1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
         }
         if (use_bf16) {
-            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, m, nb, G, ld));
+            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, m, nb, G, ld, split2));
         } else if (use_fused) {
             LAUNCHCHK(launch_csdm_fused(lc(), Xs, Xt, nch, m, nb, G, ld));
         } else if (use_mfma) {

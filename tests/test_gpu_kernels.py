@@ -504,6 +504,35 @@ def test_csd_matrix_packed_spectra_path(E):
     assert np.max(np.abs(G1[:, :3, :3] - ref)) <= 2e-5 * np.abs(ref).max()
 
 
+def test_csd_matrix_two_piece_contraction(E):
+    """From 1024 frame pairs on the contraction splits its operands into two bf16 pieces (16 bits) instead of three: against
+    the three-piece form (SP_CSDM_SPLIT3=1) and the float64 oracle, on noise and on a line whose spectrum repeats from frame
+    to frame (the case where the operand rounding does not average out)"""
+    import os
+    nfft, hop, nch, M = 4096, 2048, 16, 2051
+    nsig = (M - 1) * hop + nfft
+    win = O.windows("Hanning", nwins=nfft)
+    rng = np.random.default_rng(31)
+    t = np.arange(nsig)
+    for kind in (0, 1):
+        if kind == 0:
+            x = (rng.standard_normal((nch, nsig)) + 0.7 * rng.standard_normal(nsig)[None, :] + 0.3).astype(np.float32)
+        else:
+            x = np.stack([np.sin(2 * np.pi * 200 * t / nfft + 0.1 * c) * (1 + 0.01 * c) for c in range(nch)])
+            x = (x + 1e-3 * rng.standard_normal((nch, nsig))).astype(np.float32)
+        G2 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+        os.environ["SP_CSDM_SPLIT3"] = "1"
+        try:
+            G3 = E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+        finally:
+            del os.environ["SP_CSDM_SPLIT3"]
+        assert np.max(np.abs(G2 - G3)) > 0                                  # (two different kernels ran)
+        assert np.max(np.abs(G2 - G3)) <= 5e-6 * np.abs(G3).max(), kind
+        ref = O.csd_matrix(x[:2].astype(np.float64), win, nfft, hop, M, 1.0) * np.sum(win ** 2)
+        assert np.max(np.abs(G2[:, :2, :2] - ref)) <= 5e-6 * np.abs(ref).max(), kind
+        assert np.max(np.abs(G3[:, :2, :2] - ref)) <= 5e-6 * np.abs(ref).max(), kind
+
+
 def test_welch_csd_real_pair_equals_plain(E):
     import os
     rng = np.random.default_rng(8)

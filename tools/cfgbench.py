@@ -85,6 +85,13 @@ def main():
         flops = (nfft // 2 + 1) * nch * nch * 8.0 * M
         print("%-34s %9.3f ms  input %.0f GB/s, contraction %.1f TFLOP/s (of 157 fp32)  %8.1f Msamples/s" %
               ("cfg5 csd matrix 64ch x 2^24", ms, 4.0 * nch * n / ms / 1e6, flops / ms / 1e9, nch * n / ms / 1e3), flush=True)
+        # the same call 5 times back to back (no idle gap between the calls: clocks stay up), mean per call
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+        torch.cuda.synchronize()
+        print("%-34s %9.3f ms  per call" % ("cfg5 csd matrix, 5 back to back", (time.perf_counter() - t0) / 5 * 1e3), flush=True)
         ms, out = timed(lambda: E.welch_csd(x[0], x[1:], win, hop, M, detrend=True, sided=E.SIDED_ONE, scale=1.0), 2)
         report("cfg5 ref x 63 channels csd", ms, 4.0 * nch * n, nch * n, "samples")
         del x, G
