@@ -452,9 +452,16 @@ template <int N> struct FftPlan {
 // 16-row table in LDS (`tw1`: row = tid % 16, SP_TW1_PITCH floats apart) -- only 16 distinct sets exist for that pass; frees
 // 40 VGPRs per thread (the occupancy experiment of the carry kernel, SP_CARRY_W3)
 #define SP_TW1_PITCH 44      /* 40 floats + 4: rows start 44 dwords apart -> the 16 rows of a b128 read hit 16 distinct bank quads */
-template <int N, bool TW1LDS = false> struct WgFft {
+// RM: the first exchange image holds every thread's 16 pass-0 outputs side by side, [thread][16] at a pitch of RM_PITCH, the
+// four outputs of a final radix-4 butterfly (k = c, c+4, c+8, c+12) adjacent: two 16-byte writes instead of four 8-byte ones
+// (the [k][thread] image at pitch T + 1 takes 16 single ds_write_b64: its stride fits neither write2 form), and the unit-
+// stride gather of the next pass strides 16 RM_PITCH = 5 x 64 elements, a ds_read2st64_b64 per two elements as before.
+template <int N, bool TW1LDS = false, bool RM = false> struct WgFft {
     using PL = FftPlan<N>;
     static constexpr int R = PL::R, T = PL::T, NP = PL::NP;
+    static constexpr int RM_PITCH = 20;
+    static constexpr int IMG0 = RM ? T * RM_PITCH : PL::LDS_ELEMS;      // elements of a first-exchange image
+    static_assert(!RM || (PL::radix(0) == 16 && R == 16 && (T % 16) == 0), "RM: radix-16 first pass");
     static constexpr int N16 = PL::NP16 > 1 ? PL::NP16 - 1 : 0;          // twiddled radix-16 passes
     static constexpr int NTR = (N >= 16 && PL::REM > 1) ? (R / PL::REM) * (PL::REM - 1) : 0;   // remainder-pass twiddles
 #if SP_PACKED
@@ -536,7 +543,8 @@ template <int N, bool TW1LDS = false> struct WgFft {
 
     // physical LDS index of logical element i for exchange number E (0 = first)
     template <int E> static __device__ __forceinline__ int phys(int i) {
-        if constexpr (E == 0) return (i % PL::radix(0)) * PL::PITCH1 + i / PL::radix(0);
+        if constexpr (E == 0 && RM) return (i / 16) * RM_PITCH + (i % 4) * 4 + (i % 16) / 4;
+        else if constexpr (E == 0) return (i % PL::radix(0)) * PL::PITCH1 + i / PL::radix(0);
         else return i;
     }
 
@@ -598,7 +606,12 @@ template <int N, bool TW1LDS = false> struct WgFft {
     }
     // unit-stride gather from exchange image P: v[t] = element tid + T*t
     template <int P> __device__ __forceinline__ void gather(cf (&v)[R], const cf *lds, int tid) const {
-        if constexpr (P == 0 && (T % 16) == 0 && PL::radix(0) == 16) {
+        if constexpr (P == 0 && RM) {
+            // i = tid + T*t  ->  (tid/16 + (T/16) t) * RM_PITCH + pos(tid % 16)
+            const int b = (tid / 16) * RM_PITCH + (tid % 4) * 4 + (tid % 16) / 4;
+#pragma unroll
+            for (int t = 0; t < R; ++t) v[t] = lds_load_single(&lds[b + (T / 16) * RM_PITCH * t]);
+        } else if constexpr (P == 0 && (T % 16) == 0 && PL::radix(0) == 16) {
             // i = tid + T*t  ->  (i%16)*PITCH1 + i/16 = (tid%16)*PITCH1 + tid/16 + (T/16)*t
             const int b = (tid % 16) * PL::PITCH1 + tid / 16;
 #pragma unroll

@@ -39,6 +39,9 @@
 #ifndef SP_PIPE_AHEAD
 #define SP_PIPE_AHEAD 2
 #endif
+#ifndef SP_PIPE_RM
+#define SP_PIPE_RM 0          // 1: first exchange image [thread][16] (fft_core.h, WgFft RM): 16-byte scatter writes
+#endif
 namespace sp {
 
 #if !SP_PACKED
@@ -62,8 +65,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
     float *trend = SPEC ? trend_in + 4 * blockIdx.y : trend_in;
     static_assert(!RP || (!CPLX && SHIFT == 8), "the real-pair form is for real input at hop = nfft / 2");
     using PL = FftPlan<N>;
-    using F = WgFft<N>;
-    constexpr int T = PL::T, R = PL::R, KEEP = R - SHIFT, IMG = PL::LDS_ELEMS;
+    using F = WgFft<N, false, SP_PIPE_RM != 0>;
+    constexpr int T = PL::T, R = PL::R, KEEP = R - SHIFT, IMG = F::IMG0, IMGB = SP_PIPE_RM ? N : PL::LDS_ELEMS;
     static_assert(T == 256 && R == 16 && PL::NP == 3, "three radix-16 passes over 256 threads");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *smem = reinterpret_cast<cf *>(smem_raw);
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
         };
         for (int64_t p = 0; p < periods; p += 2) {
             step(va, vb, p, imgA + IMG, imgB);
-            if (p + 1 < periods) step(vb, va, p + 1, imgA, imgB + IMG);
+            if (p + 1 < periods) step(vb, va, p + 1, imgA, imgB + IMGB);
         }
     } else {
         if constexpr (SP_PIPE_PRIO) __builtin_amdgcn_s_setprio(SP_PIPE_PRIO % 10);
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             PIPE_SYNC();
         };
         for (int64_t p = 0; p < periods; p += 2) {
-            step(va, vb, p, imgB + IMG);
+            step(va, vb, p, imgB + IMGB);
             if (p + 1 < periods) step(vb, va, p + 1, imgB);
         }
         if constexpr (!COG && !SPEC) {
@@ -503,7 +506,8 @@ int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, i
 #if SP_PACKED
     return -1;
 #else
-    const size_t lds = sizeof(cf) * 4 * (size_t)FftPlan<4096>::LDS_ELEMS;
+    const size_t lds = SP_PIPE_RM ? sizeof(cf) * 2 * (size_t)(WgFft<4096, false, true>::IMG0 + 4096)
+                                  : sizeof(cf) * 4 * (size_t)FftPlan<4096>::LDS_ELEMS;
 #define PIPE_(CP, S, OP)                                                                                  \
     {                                                                                                 \
         static bool once = false;                                                                     \
