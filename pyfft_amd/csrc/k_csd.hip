@@ -72,17 +72,24 @@ int launch_pairspec(LaunchCtx c, const float *x, const float *win, int hop, int6
 }
 
 int launch_csd_pair(LaunchCtx c, const float *y, int nch, int64_t y_ld, const float *win, int hop, int64_t nframes,
-                    const float *trend_y, bool lin, const Xf &xf, const cf *Zx, float *partial, const RunPart &rp) {
+                    float *trend_y, bool lin, const Xf &xf, const cf *Zx, float *partial, const RunPart &rp, cf *spartial) {
     const int cf_ = (rp.blocks <= 65535 && !getenv("SP_CSD_RUNFAST")) ? 1 : 0;       // channel-fastest block order (grid.y <= 65535)
     const dim3 grid_ = cf_ ? dim3(nch, rp.blocks) : dim3(rp.blocks, nch);
+    if (spartial) {
+        // one-pass mean detrend (see the kernel): nfft 4096 at hop 2048 only
+        if (lin || xf.L != 4096 || hop != 2048) return -1;
+        hipLaunchKernelGGL((k_welch_csd_pair<4096, false, true>), grid_, dim3(WgCfg<4096>::WG), WgCfg<4096>::lds_bytes(1), c.stream, y,
+                           y_ld, win, hop, nframes, rp.fpg, trend_y, xf.tb, Zx, partial, rp.groups, cf_, spartial);
+        return 0;
+    }
 #define CP_(NN)                                                                                       \
     case NN:                                                                                          \
         if (lin) hipLaunchKernelGGL((k_welch_csd_pair<NN, true>), grid_, dim3(WgCfg<NN>::WG),         \
                                     WgCfg<NN>::lds_bytes(1), c.stream, y, y_ld, win, hop, nframes, rp.fpg, trend_y, xf.tb, Zx, \
-                                    partial, rp.groups, cf_);                                         \
+                                    partial, rp.groups, cf_, (cf *)nullptr);                          \
         else hipLaunchKernelGGL((k_welch_csd_pair<NN, false>), grid_, dim3(WgCfg<NN>::WG),            \
                                 WgCfg<NN>::lds_bytes(1), c.stream, y, y_ld, win, hop, nframes, rp.fpg, trend_y, xf.tb, Zx,     \
-                                partial, rp.groups, cf_);                                             \
+                                partial, rp.groups, cf_, (cf *)nullptr);                              \
         break;
     switch (xf.L) {
         CP_(32) CP_(64) CP_(128) CP_(256) CP_(512) CP_(1024) CP_(2048) CP_(4096) CP_(8192)
@@ -93,10 +100,16 @@ int launch_csd_pair(LaunchCtx c, const float *y, int nch, int64_t y_ld, const fl
 }
 
 int launch_csd_pair_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
-                           double *pyy, double *pxy) {
+                           double *pyy, double *pxy, const double *st_y, const double *st_x, const cf *Wf, const float *trend_x,
+                           const float *trend_y, int64_t nmean, int64_t M) {
     const int n = xf.tb.n;
     hipLaunchKernelGGL(k_csd_pair_finish, dim3((n + SP_FIN_BINS - 1) / SP_FIN_BINS, nch), dim3(SP_FIN_BINS * SP_FIN_SLICES), 0,
-                       c.stream, partial, G, n, nch, sided, scale, pyy, pxy);
+                       c.stream, partial, G, n, nch, sided, scale, pyy, pxy, st_y, st_x, Wf, trend_x, trend_y, nmean, M);
+    return 0;
+}
+// block sums of one real signal (zeroed Sl of 2 H doubles), see k_colsum_real
+int launch_colsum_real(LaunchCtx c, const float *x, const float *trend, int H, int64_t M, double *Sl) {
+    hipLaunchKernelGGL(k_colsum_real, dim3((H + 255) / 256, 64), dim3(256), 0, c.stream, x, trend, H, M, Sl);
     return 0;
 }
 

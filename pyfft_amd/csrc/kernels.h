@@ -1569,15 +1569,19 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_pairspec(const float *__restri
     }
 }
 
-template <int N, bool LIN>
-__global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd_pair(const float *__restrict__ y, int64_t y_ld,
+// OP (mean detrend in one pass, hop = N/2, one transform per workgroup): every workgroup of a channel forms the same estimate
+// mu0 of the channel's mean (16 runs of WG samples), detrends by it and leaves the block sums of its frames' last hop-blocks in
+// spartial[ch][group][hop]; the finish kernel corrects with the exact mean (k_csd_pair_finish).  Workgroup 0 publishes mu0.
+template <int N, bool LIN, bool OP = false>
+__global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu(OP ? 2 : 1, OP ? 2 : 8))) void k_welch_csd_pair(const float *__restrict__ y, int64_t y_ld,
                                                                   const float *__restrict__ win, int hop, int64_t nframes,
-                                                                  int64_t ppg, const float *__restrict__ trend_y, XfTables tb,
+                                                                  int64_t ppg, float *__restrict__ trend_y, XfTables tb,
                                                                   const cf *__restrict__ Zx, float *__restrict__ partial,
-                                                                  int64_t groups_total, int chan_fast) {
+                                                                  int64_t groups_total, int chan_fast, cf *__restrict__ spartial) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
+    static_assert(!OP || (!LIN && WgCfg<N>::FPW == 1 && (C::R % 2) == 0), "one-pass form: mean detrend, one transform per workgroup");
     // chan_fast: the channel is the fastest-varying block index, so that the workgroups resident at any time are the same few
     // runs of pairs of ALL channels and share the reference's pair spectra Zx through the L2s (with the run fastest every
     // channel streamed its own copy of the 134 MB from the Infinity Cache: 8.4 GB at 63 channels)
@@ -1591,8 +1595,40 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd_pair(const float *__
         aa[t] = 0.f;
         cc[t] = mk(0.f, 0.f);
     }
-    const Trend tr = load_trend(trend_y + 4 * ch);
     const float *yc = y + (int64_t)ch * y_ld;
+    Trend tr;
+    float sacc[OP ? C::R / 2 : 1];
+    if constexpr (OP) {
+        const int64_t span = (nframes - 1) * (int64_t)hop + N;
+        const int64_t pitch = span / 16;
+        float sx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int64_t i = pitch * r + (int64_t)threadIdx.x;
+            i = i < span ? i : span - 1;
+            sx += yc[i];
+        }
+        sx = wave_sum64(sx);
+        float *red = reinterpret_cast<float *>(smem);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sx;
+        __syncthreads();
+        double tx = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < C::WG / 64; ++wv) tx += (double)red[wv];
+        __syncthreads();
+        tr.m = mk((float)(tx / (16.0 * C::WG)), 0.f);
+        tr.s = mk(0.f, 0.f);
+        if (bx == 0 && threadIdx.x == 0) {
+            trend_y[4 * ch] = tr.m.x;
+            trend_y[4 * ch + 1] = 0.f;
+            trend_y[4 * ch + 2] = 0.f;
+            trend_y[4 * ch + 3] = 0.f;
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < C::R / 2; ++s2) sacc[s2] = 0.f;
+    } else {
+        tr = load_trend(trend_y + 4 * ch);
+    }
     const int64_t npairs = (nframes + 1) / 2;
     const int64_t gid = (int64_t)bx * C::FPW + grp;
     const int64_t p0 = gid * ppg;
@@ -1627,6 +1663,9 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd_pair(const float *__
             const cf a = detrended<LIN>(mk(raw[t].x, 0.f), tr, base_a + j);
             const cf b = detrended<LIN>(mk(raw[t].y, 0.f), tr, base_b + j);
             v[t] = mk(w[t] * a.x, kb * w[t] * b.x);
+            if constexpr (OP) {
+                if (t >= C::R / 2) sacc[t - C::R / 2] += keep * (a.x + kb * b.x);       // last hop-block of both frames
+            }
         }
         // in flight during the transform: the samples of the next pair (the reference's spectrum of this pair is read
         // after it: with both in flight the kernel needs 261 VGPRs = one wave per SIMD)
@@ -1654,13 +1693,40 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd_pair(const float *__
         p[N + k] = cc[t].x;
         p[2 * N + k] = cc[t].y;
     }
+    if constexpr (OP) {
+#pragma unroll
+        for (int s2 = 0; s2 < C::R / 2; ++s2)
+            spartial[((int64_t)ch * groups_total + gid) * hop + tid + C::T * s2] = mk(sacc[s2], 0.f);
+    }
+}
+
+// Sl[2 j] += sum over the hop-blocks b = 1 .. M of (x[b H + j] - mu): the block sums of ONE real signal (the reference of the
+// one-pass pair path), frame slices in blockIdx.y adding with float64 atomics into the zeroed Sl
+static __global__ void k_colsum_real(const float *__restrict__ x, const float *__restrict__ trend, int H, int64_t M, double *__restrict__ Sl) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= H) return;
+    const float mu = trend[0];
+    const int64_t per = (M + gridDim.y - 1) / gridDim.y;
+    const int64_t b0 = 1 + (int64_t)blockIdx.y * per, b1 = b0 + per < M + 1 ? b0 + per : M + 1;
+    double a = 0.0;
+    for (int64_t b = b0; b < b1; ++b) a += (double)(x[b * H + j] - mu);
+    if (b0 < b1) atomicAdd(&Sl[2 * j], a);
 }
 
 // pyy[ch][slot] = (a[k] + a[n-k]) / 2,  pxy[ch][slot] = (A[k] + conj(A[n-k])) / 2, scaled / doubled per sidedness
+// st_y != null (one-pass mean detrend): the channels were detrended by estimates mu0; with d = mean - mu0 (real), W = FFT(window),
+// B = sum_g of the spectra (k_op_finish<EXPORT> states st_y[ch], st_x), M frames, nmean samples per signal:
+//   sum |Y - dy W|^2 = a - 2 Re(conj(dy W) By) + M |dy W|^2,   sum (Y - dy W) conj(X - dx W) = A - dx conj(W) By - dy W conj(Bx) + M dx dy |W|^2
 static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_pair_finish(const float *__restrict__ partial,
                                                                                  int64_t G, int n, int nch, int sided,
                                                                                  double scale, double *__restrict__ pyy,
-                                                                                 double *__restrict__ pxy) {
+                                                                                 double *__restrict__ pxy,
+                                                                                 const double *__restrict__ st_y,
+                                                                                 const double *__restrict__ st_x,
+                                                                                 const cf *__restrict__ Wf,
+                                                                                 const float *__restrict__ trend_x,
+                                                                                 const float *__restrict__ trend_y, int64_t nmean,
+                                                                                 int64_t M) {
     __shared__ double sh[6][SP_FIN_SLICES][SP_FIN_BINS];
     const int lane = threadIdx.x % SP_FIN_BINS, sl = threadIdx.x / SP_FIN_BINS;
     const int k = blockIdx.x * SP_FIN_BINS + lane;
@@ -1689,9 +1755,21 @@ static __global__ __launch_bounds__(SP_FIN_BINS *SP_FIN_SLICES) void k_csd_pair_
 #pragma unroll
             for (int j = 0; j < 6; ++j) t[j] = sh[j][0][lane];
             const double m = 0.5 * scale * (bin_doubled(k, n, sided) ? 2.0 : 1.0);
-            pyy[(int64_t)ch * nb + slot] = (t[0] + t[1]) * m;
-            pxy[((int64_t)ch * nb + slot) * 2] = (t[2] + t[4]) * m;
-            pxy[((int64_t)ch * nb + slot) * 2 + 1] = (t[3] - t[5]) * m;
+            double cyy = 0.0, cr = 0.0, ci = 0.0;
+            if (st_y) {
+                const int64_t ss = (int64_t)5 * n + 8;
+                const double *sy = st_y + ch * ss;
+                const double dy = sy[5 * n + 3] / (double)nmean - (double)trend_y[4 * ch];
+                const double dx = st_x[5 * n + 3] / (double)nmean - (double)trend_x[0];
+                const double wr = Wf[k].x, wi = Wf[k].y, w2 = wr * wr + wi * wi;
+                const double byr = sy[n + 2 * k], byi = sy[n + 2 * k + 1], bxr = st_x[n + 2 * k], bxi = st_x[n + 2 * k + 1];
+                cyy = -2.0 * dy * (wr * byr + wi * byi) + (double)M * dy * dy * w2;
+                cr = -dx * (wr * byr + wi * byi) - dy * (wr * bxr + wi * bxi) + (double)M * dx * dy * w2;
+                ci = -dx * (wr * byi - wi * byr) - dy * (wi * bxr - wr * bxi);
+            }
+            pyy[(int64_t)ch * nb + slot] = (t[0] + t[1] + 2.0 * cyy) * m;
+            pxy[((int64_t)ch * nb + slot) * 2] = (t[2] + t[4] + 2.0 * cr) * m;
+            pxy[((int64_t)ch * nb + slot) * 2 + 1] = (t[3] - t[5] + 2.0 * ci) * m;
         }
     }
 }

@@ -1130,7 +1130,16 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     TrendBuf tb;
     if (get_trendbuf(nch + 1, &tb)) return -1;
     if (set_trend(tb, 0, xd, cplx, nsig, detrend, mean_x ? mean_x[0] : 0, mean_x ? mean_x[1] : 0)) return -1;
-    if (detrend != 0 && nch <= 512) {
+    // real x against many real channels: the pair path below; with mean detrend at nfft 4096 / 50 % overlap the channels' means
+    // are not taken by a pass of their own (4.2 GB at 63 channels x 2^24: 0.7 of 2.9 ms) but in one pass with the spectra
+    // (k_welch_csd_pair<OP>: estimate + block sums, exact correction in k_csd_pair_finish); SP_CSD_TWOPASS=1: the separate pass
+    const bool pair_path = !lng && !cplx && !segmean && csd_rp_eligible(xf) && nch >= 2 && nframes >= 2 && !env_flag("SP_NO_REALPAIR") &&
+                           !env_flag("SP_CSD_XIY");
+    const bool pair_op = pair_path && detrend == SP_DETREND_MEAN && xf.L == 4096 && 2 * hop == xf.L && nch <= 512 &&
+                         !env_flag("SP_CSD_TWOPASS");
+    if (pair_op) {
+        HIPCHK(hipMemsetAsync(tb.f + 4, 0, sizeof(float) * 4 * (size_t)nch, g.stream));     // (the kernel publishes its estimates here)
+    } else if (detrend != 0 && nch <= 512) {
         // all channels' means / trend lines in one launch pair (64 channels one by one cost 3 ms of launches)
         double *scr = moments_scratch();
         if (!scr) return -1;
@@ -1187,8 +1196,7 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     const RunPart rp = run_partition_2d(xf.L, nframes, g.ncu, nch);
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L * 4 * (size_t)nch)) return -1;
     float *partial = (float *)g.work.p;
-    if (!cplx && !segmean && csd_rp_eligible(xf) && nch >= 2 && nframes >= 2 && !env_flag("SP_NO_REALPAIR") &&
-        !env_flag("SP_CSD_XIY")) {
+    if (pair_path) {
         // real x against many real channels: the reference's packed pair spectra once, then one transform per
         // (channel, frame PAIR); Pxx from the real-pair PSD kernel.  (SP_CSD_XIY=1: the x + i y_c form below.)
         const int64_t npairs = (nframes + 1) / 2;
@@ -1199,9 +1207,33 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         cf *Zx = (cf *)g.cmS.p;
         const RunPart rpx = run_partition(xf.L, npairs, g.ncu);
         LAUNCHCHK(launch_pairspec(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rpx, Zx));
-        LAUNCHCHK(launch_csd_pair(lc(), (const float *)yd, nch, y_ld, (const float *)win_d, hop, nframes, tb.f + 4, detrend == 2,
-                                  xf, Zx, partial, rpp));
-        LAUNCHCHK(launch_csd_pair_finish(lc(), partial, rpp.groups, xf, nch, sided, scale / (double)nframes, pyy_d, pxy_d));
+        if (pair_op) {
+            const size_t N5 = (size_t)(5 * nfft + 8);
+            const size_t b_sp = sizeof(cf) * (size_t)nch * (size_t)rpp.groups * (size_t)hop;
+            const size_t b_sl = sizeof(double) * 2 * (size_t)hop * (size_t)(nch + 1), b_st = sizeof(double) * N5 * (size_t)(nch + 1);
+            if (g.cmO.ensure(b_sp + b_sl + b_st)) return -1;
+            cf *spartial = (cf *)g.cmO.p;
+            double *Sl = (double *)((char *)g.cmO.p + b_sp), *Slx = Sl + 2 * (size_t)hop * (size_t)nch;
+            double *st = (double *)((char *)g.cmO.p + b_sp + b_sl), *stx = st + N5 * (size_t)nch;
+            void *Wf_d;
+            if (get_window_spectrum(win, nfft, xf, &Wf_d)) return -1;
+            LAUNCHCHK(launch_csd_pair(lc(), (const float *)yd, nch, y_ld, (const float *)win_d, hop, nframes, tb.f + 4, false, xf, Zx,
+                                      partial, rpp, spartial));
+            LAUNCHCHK(launch_cm_blocksums(lc(), spartial, nch, (int)rpp.groups, hop, Sl));
+            LAUNCHCHK(launch_op_finish_channels(lc(), (const float *)yd, y_ld, nch, tb.f + 4, (const float *)win_d, Sl, (const cf *)Wf_d,
+                                                hop, nframes, nsig, xf, st));
+            // the reference (detrended by its exact mean: its d is rounding only, but B_x is needed for the channels' terms)
+            HIPCHK(hipMemsetAsync(Slx, 0, sizeof(double) * 2 * (size_t)hop, g.stream));
+            LAUNCHCHK(launch_colsum_real(lc(), (const float *)xd, tb.f, hop, nframes, Slx));
+            LAUNCHCHK(launch_op_finish_channels(lc(), (const float *)xd, 0, 1, tb.f, (const float *)win_d, Slx, (const cf *)Wf_d, hop,
+                                                nframes, nsig, xf, stx));
+            LAUNCHCHK(launch_csd_pair_finish(lc(), partial, rpp.groups, xf, nch, sided, scale / (double)nframes, pyy_d, pxy_d, st, stx,
+                                             (const cf *)Wf_d, tb.f, tb.f + 4, nsig, nframes));
+        } else {
+            LAUNCHCHK(launch_csd_pair(lc(), (const float *)yd, nch, y_ld, (const float *)win_d, hop, nframes, tb.f + 4, detrend == 2,
+                                      xf, Zx, partial, rpp));
+            LAUNCHCHK(launch_csd_pair_finish(lc(), partial, rpp.groups, xf, nch, sided, scale / (double)nframes, pyy_d, pxy_d));
+        }
         // Pxx: real-pair Welch PSD of x (its own small partial buffer after the channels' one)
         if (g.bigT.ensure(sizeof(float) * (size_t)rpx.groups * xf.L)) return -1;
         float *px = (float *)g.bigT.p;

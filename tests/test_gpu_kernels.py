@@ -738,6 +738,39 @@ def test_welch_csd_reference_once_path(E, nfft, hop, n, nch, detrend, monkeypatc
         assert np.max(np.abs(v - w)) <= 3e-5 * np.abs(w).max()
 
 
+@pytest.mark.parametrize("M,tail,nch", [(301, 0, 5), (300, 777, 3), (2051, 5000, 2)])
+def test_welch_csd_reference_once_one_pass_means(E, M, tail, nch, monkeypatch):
+    """reference against >= 2 real channels at nfft 4096 / 50 % overlap with mean detrend: the channels' means are taken in the
+    pass that forms the spectra (estimate + block sums + exact correction in the finish kernel).  Against the separate mean
+    pass (SP_CSD_TWOPASS=1) and the float64 oracle; channel offsets far above the noise, samples after the last frame (they
+    count for the mean), odd and even frame counts"""
+    nfft, hop = 4096, 2048
+    n = (M - 1) * hop + nfft + tail
+    rng = np.random.default_rng(M + nch)
+    k = np.arange(n)
+    x = (np.sin(0.11 * k) + 0.3 * rng.standard_normal(n) - 0.4).astype(np.float32)
+    y = np.stack([0.5 * np.sin(0.11 * k + 0.3 * c) + 0.2 * rng.standard_normal(n) + 1.5 * (c + 1) for c in range(nch)]).astype(np.float32)
+    win = O.windows("Hanning", nwins=nfft)
+    for sided in (E.SIDED_TWO, E.SIDED_ONE, E.SIDED_RAW):
+        a = E.welch_csd(x, y, win, hop, M, detrend=True, sided=sided, scale=1.0)
+        monkeypatch.setenv("SP_CSD_TWOPASS", "1")
+        b = E.welch_csd(x, y, win, hop, M, detrend=True, sided=sided, scale=1.0)
+        monkeypatch.delenv("SP_CSD_TWOPASS")
+        for u, v in zip(a, b):
+            assert np.max(np.abs(u - v)) <= 3e-6 * np.abs(v).max()
+        assert any(np.max(np.abs(u - v)) > 0 for u, v in zip(a, b))           # (two different paths ran)
+    pxx, pyy, pxy = E.welch_csd(x, y, win, hop, M, detrend=True, sided=E.SIDED_RAW, scale=1.0)       # (unshifted bins)
+    x64 = x.astype(np.float64) - x.astype(np.float64).mean()
+    y64 = y.astype(np.float64) - y.astype(np.float64).mean(axis=1, keepdims=True)
+    fx = np.stack([np.fft.fft(win * x64[g * hop:g * hop + nfft]) for g in range(M)])
+    for c in range(nch):
+        fy = np.stack([np.fft.fft(win * y64[c, g * hop:g * hop + nfft]) for g in range(M)])
+        ryy = np.mean(np.abs(fy) ** 2, axis=0)
+        rxy = np.mean(fy * np.conj(fx), axis=0)
+        assert np.max(np.abs(pyy[c] - ryy)) <= 2e-5 * ryy.max()
+        assert np.max(np.abs(pxy[c] - rxy)) <= 2e-5 * np.abs(rxy).max()
+
+
 # ---------------------------------------------------------------- A6 / N1 epilogue on device-resident spectra
 @pytest.mark.parametrize("nfft,onesided", [(1024, True), (1333, True), (512, False), (777, False)])
 def test_csd_epilogue_on_device(E, nfft, onesided):
