@@ -35,13 +35,16 @@ int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t n
     const int fpw = fpw_of(xf.L);
     if (ncols % fpw || nouter < 1) return -1;
     const int64_t ncb = ncols / fpw, total = ncb * nouter;
-    const int64_t cap = (int64_t)c.ncu * 4;                    // several blocks per workgroup amortise its twiddle set-up
+    // (a multiple of the 2 or 3 workgroups a CU holds, so that the last round is a full one)
+    const int64_t cap = (int64_t)c.ncu * 6;                    // several blocks per workgroup amortise its twiddle set-up
     const unsigned grid = (unsigned)(total < cap ? total : cap);
 #define M_(XT)                                                                                        \
     if (ci.kind == 1) hipLaunchKernelGGL((k_fft_cols<XT::L, 1>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, \
                                          ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);                 \
     else if (ci.kind == 3) hipLaunchKernelGGL((k_fft_cols<XT::L, 3>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, \
                                               out, ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);       \
+    else if (hmask_n > 0) hipLaunchKernelGGL((k_fft_cols<XT::L, 0, true>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, \
+                                             in, out, ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);           \
     else hipLaunchKernelGGL((k_fft_cols<XT::L, 0>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, ncb, nouter, \
                             es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);
     SP_DISPATCH_P(xf, M_)

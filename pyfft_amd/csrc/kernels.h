@@ -402,8 +402,16 @@ struct ColsIn {
     const double *mom;
     int64_t nreal;
 };
-template <int L, int KIND>   // KIND = ci.kind as a template parameter: as a run-time branch the load forms cost 306 VGPRs
-__global__ __launch_bounds__(WgCfg<L>::WG, 2) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
+// HM: the analytic-signal mask of the full-length Hilbert inverse (hmask_n > 0) as a template flag too -- its sixteen 64-bit bin
+// indices cost 65 VGPRs; without it the plain form (KIND 0) fits 3 waves per SIMD (166 VGPRs), i.e. three workgroups per CU
+// instead of two to cover the load round trips of this unpipelined loop (SP_COLS_WAVES)
+#ifndef SP_COLS_WAVES
+#define SP_COLS_WAVES 3
+#endif
+template <int L, int KIND, bool HM = false>   // KIND = ci.kind as a template parameter: as a run-time branch the load forms cost 306 VGPRs
+__global__ __launch_bounds__(WgCfg<L>::WG)
+    __attribute__((amdgpu_waves_per_eu((KIND == 0 && !HM && L <= 256) ? SP_COLS_WAVES : 2,
+                                       (KIND == 0 && !HM && L <= 256) ? SP_COLS_WAVES : 2))) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
                                                             int64_t nouter, int64_t es, int64_t os, int64_t twmul, int conj_in,
                                                             XfTables tb, BigTw bt, int64_t hmask_n, ColsIn ci) {
     using X = XfPow2<L>;
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(WgCfg<L>::WG, 2) void k_fft_cols(const cf *__restri
 #pragma unroll
             for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
         }
-        if (hmask_n > 0) {
+        if (HM && hmask_n > 0) {
             // analytic-signal mask (hilbert.py:63-64) applied while loading the spectrum for the inverse transform
             // (pass 1 only: base + i*es is the bin index): k = 0 and k = nyq x1, 1..nyq-1 x2, above x0
             const int64_t nyq = (hmask_n & 1) ? (hmask_n + 1) / 2 : hmask_n / 2;
