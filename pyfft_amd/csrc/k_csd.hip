@@ -107,9 +107,9 @@ int launch_csd_pair_finish(LaunchCtx c, const float *partial, int64_t G, const X
                        c.stream, partial, G, n, nch, sided, scale, pyy, pxy, st_y, st_x, Wf, trend_x, trend_y, nmean, M);
     return 0;
 }
-// block sums of one real signal (zeroed Sl of 2 H doubles), see k_colsum_real
-int launch_colsum_real(LaunchCtx c, const float *x, const float *trend, int H, int64_t M, double *Sl) {
-    hipLaunchKernelGGL(k_colsum_real, dim3((H + 255) / 256, 64), dim3(256), 0, c.stream, x, trend, H, M, Sl);
+// block sums of one real signal in SP_COLSUM_SLICES slices (out: [slices][H] complex), see k_colsum_real
+int launch_colsum_real(LaunchCtx c, const float *x, const float *trend, int H, int64_t M, cf *out) {
+    hipLaunchKernelGGL(k_colsum_real, dim3((H + 255) / 256, SP_COLSUM_SLICES), dim3(256), 0, c.stream, x, trend, H, M, out);
     return 0;
 }
 

@@ -1708,9 +1708,9 @@ __global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu(OP
     }
 }
 
-// Sl[2 j] += sum over the hop-blocks b = 1 .. M of (x[b H + j] - mu): the block sums of ONE real signal (the reference of the
-// one-pass pair path), frame slices in blockIdx.y adding with float64 atomics into the zeroed Sl
-static __global__ void k_colsum_real(const float *__restrict__ x, const float *__restrict__ trend, int H, int64_t M, double *__restrict__ Sl) {
+// block sums of ONE real signal (the reference of the one-pass pair path): slice blockIdx.y of the hop-blocks b = 1 .. M writes
+// out[slice][j] = sum_b (x[b H + j] - mu); k_cm_blocksums adds the slices in a fixed order (no atomics: reproducible)
+static __global__ void k_colsum_real(const float *__restrict__ x, const float *__restrict__ trend, int H, int64_t M, cf *__restrict__ out) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= H) return;
     const float mu = trend[0];
@@ -1718,7 +1718,7 @@ static __global__ void k_colsum_real(const float *__restrict__ x, const float *_
     const int64_t b0 = 1 + (int64_t)blockIdx.y * per, b1 = b0 + per < M + 1 ? b0 + per : M + 1;
     double a = 0.0;
     for (int64_t b = b0; b < b1; ++b) a += (double)(x[b * H + j] - mu);
-    if (b0 < b1) atomicAdd(&Sl[2 * j], a);
+    out[(int64_t)blockIdx.y * H + j] = mk((float)a, 0.f);
 }
 
 // pyy[ch][slot] = (a[k] + a[n-k]) / 2,  pxy[ch][slot] = (A[k] + conj(A[n-k])) / 2, scaled / doubled per sidedness

@@ -613,11 +613,15 @@ static int welch_pipe_gpc() {
     }();
     return v;
 }
-static bool welch_pipe_wanted(const Xf &xf, int hop, int64_t nframes) {
+static int welch_pipe_mode() {
     static const int mode = [] {
         const char *e = getenv("SP_WELCH_PIPE");
         return e ? atoi(e) : SP_WELCH_PIPE_DEFAULT;
     }();
+    return mode;
+}
+static bool welch_pipe_wanted(const Xf &xf, int hop, int64_t nframes) {
+    const int mode = welch_pipe_mode();
     return welch_pipe_eligible(xf, hop) && (mode >= 2 || (mode == 1 && nframes >= 32 * (int64_t)g.ncu));
 }
 
@@ -641,7 +645,10 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     // real input at hop = nfft/2: two frames per transform on the pipeline (k_welch_pipe modes 3/4), partitioned over frame PAIRS
     const bool realpair = !cplx && 2 * hop == nfft && nframes >= 2 && !env_flag("SP_NO_REALPAIR") &&
                           welch_pipe_wanted(xf, hop, (nframes + 1) / 2);
-    const bool pipe = realpair || welch_pipe_wanted(xf, hop, nframes);
+    // (not at hop = nfft: the one-pass front role with 16 new samples per thread and their block sums spills 20 registers and
+    //  runs at half the symmetric kernel's rate, 1.00 against 0.50 ms at 2^28 samples; the plain mode is faster there, 0.40 / 0.44)
+    //  (SP_WELCH_PIPE=2 still forces it: tests/test_gpu_pipe.py keeps the instantiation correct)
+    const bool pipe = realpair || ((hop != nfft || welch_pipe_mode() >= 2) && welch_pipe_wanted(xf, hop, nframes));
     const RunPart rp = realpair ? run_partition(xf.L, (nframes + 1) / 2, g.ncu, welch_pipe_gpc())
                                 : (pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc()) : run_partition(xf.L, nframes, g.ncu));
     if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
@@ -1209,7 +1216,8 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         LAUNCHCHK(launch_pairspec(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rpx, Zx));
         if (pair_op) {
             const size_t N5 = (size_t)(5 * nfft + 8);
-            const size_t b_sp = sizeof(cf) * (size_t)nch * (size_t)rpp.groups * (size_t)hop;
+            const size_t b_spy = sizeof(cf) * (size_t)nch * (size_t)rpp.groups * (size_t)hop;
+            const size_t b_sp = b_spy + sizeof(cf) * SP_COLSUM_SLICES * (size_t)hop;          // + the reference's slice sums
             const size_t b_sl = sizeof(double) * 2 * (size_t)hop * (size_t)(nch + 1), b_st = sizeof(double) * N5 * (size_t)(nch + 1);
             if (g.cmO.ensure(b_sp + b_sl + b_st)) return -1;
             cf *spartial = (cf *)g.cmO.p;
@@ -1223,8 +1231,9 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
             LAUNCHCHK(launch_op_finish_channels(lc(), (const float *)yd, y_ld, nch, tb.f + 4, (const float *)win_d, Sl, (const cf *)Wf_d,
                                                 hop, nframes, nsig, xf, st));
             // the reference (detrended by its exact mean: its d is rounding only, but B_x is needed for the channels' terms)
-            HIPCHK(hipMemsetAsync(Slx, 0, sizeof(double) * 2 * (size_t)hop, g.stream));
-            LAUNCHCHK(launch_colsum_real(lc(), (const float *)xd, tb.f, hop, nframes, Slx));
+            cf *spx = (cf *)((char *)g.cmO.p + b_spy);
+            LAUNCHCHK(launch_colsum_real(lc(), (const float *)xd, tb.f, hop, nframes, spx));
+            LAUNCHCHK(launch_cm_blocksums(lc(), spx, 1, SP_COLSUM_SLICES, hop, Slx));
             LAUNCHCHK(launch_op_finish_channels(lc(), (const float *)xd, 0, 1, tb.f, (const float *)win_d, Slx, (const cf *)Wf_d, hop,
                                                 nframes, nsig, xf, stx));
             LAUNCHCHK(launch_csd_pair_finish(lc(), partial, rpp.groups, xf, nch, sided, scale / (double)nframes, pyy_d, pxy_d, st, stx,

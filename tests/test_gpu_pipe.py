@@ -112,6 +112,13 @@ M = ((1 << 25) - 4096) // 2048 + 1
 p = E.welch_psd(x, win, 2048, M, detrend=True, sided=E.SIDED_TWO, scale=1.0).cpu().numpy()
 print("KERNEL", E.profile_last_kernel())
 np.save(sys.argv[1], p)
+# no overlap: the one-pass mean detrend stays on the symmetric kernel (the pipeline's front role spills there and ran at half
+# its rate), the plain accumulation takes the pipeline
+M0 = (1 << 25) // 4096
+q = E.welch_psd(x, win, 4096, M0, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+print("KERNEL0 onepass", E.profile_last_kernel())
+q = E.welch_psd(x, win, 4096, M0, detrend=False, sided=E.SIDED_TWO, scale=1.0)
+print("KERNEL0 plain", E.profile_last_kernel())
 """ % ROOT
     import tempfile
     import numpy as np
@@ -123,5 +130,7 @@ np.save(sys.argv[1], p)
                                capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stdout + r.stderr
             assert ("KERNEL k_welch_pipe" in r.stdout) == (mode == "1"), r.stdout
+            assert "KERNEL0 onepass k_welch_pipe" not in r.stdout, r.stdout
+            assert ("KERNEL0 plain k_welch_pipe" in r.stdout) == (mode == "1"), r.stdout
             outs[mode] = np.load(f)
     assert np.max(np.abs(outs["1"] - outs["0"])) <= 2e-5 * outs["0"].max()
