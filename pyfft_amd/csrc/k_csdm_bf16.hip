@@ -434,21 +434,39 @@ int launch_csdm_fold(LaunchCtx c, const double *H, double *G, int nch, int n, co
 }
 
 // ---- one-pass channel means for the packed-spectra path ------------------------------------------------------------------
-// Sl[ch][2j], Sl[ch][2j+1] = sum over the runs of the front role's block sums spartial[ch][run][j] (float64, fixed order)
-static __global__ void k_cm_blocksums(const cf *__restrict__ spartial, int runs, int hop, double *__restrict__ Sl) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x, ch = blockIdx.y;
-    if (j >= hop) return;
+// Sl[ch][2j], Sl[ch][2j+1] = sum over the runs of the block sums spartial[ch][run][j] (float64, fixed order).  A workgroup takes
+// 16 adjacent columns (one 128-byte line per run) in 16 run-slices, reduced through LDS by halving -- with one thread per column
+// walking all runs, a call with few channels and hundreds of runs was one long latency chain on a handful of workgroups (0.3 ms)
+static __global__ __launch_bounds__(256) void k_cm_blocksums(const cf *__restrict__ spartial, int runs, int hop, double *__restrict__ Sl) {
+    __shared__ double sa[16][17], sb[16][17];
+    const int lane = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + lane, ch = blockIdx.y;
     double a = 0.0, b = 0.0;
-    for (int r = 0; r < runs; ++r) {
-        const cf v = spartial[((int64_t)ch * runs + r) * hop + j];
-        a += (double)v.x;
-        b += (double)v.y;
+    if (j < hop) {
+#pragma unroll 4
+        for (int r = sl; r < runs; r += 16) {
+            const cf v = spartial[((int64_t)ch * runs + r) * hop + j];
+            a += (double)v.x;
+            b += (double)v.y;
+        }
     }
-    Sl[(int64_t)ch * 2 * hop + 2 * j] = a;
-    Sl[(int64_t)ch * 2 * hop + 2 * j + 1] = b;
+    sa[sl][lane] = a;
+    sb[sl][lane] = b;
+    __syncthreads();
+    for (int o = 8; o > 0; o >>= 1) {
+        if (sl < o) {
+            sa[sl][lane] += sa[sl + o][lane];
+            sb[sl][lane] += sb[sl + o][lane];
+        }
+        __syncthreads();
+    }
+    if (sl == 0 && j < hop) {
+        Sl[(int64_t)ch * 2 * hop + 2 * j] = sa[0][lane];
+        Sl[(int64_t)ch * 2 * hop + 2 * j + 1] = sb[0][lane];
+    }
 }
 int launch_cm_blocksums(LaunchCtx c, const cf *spartial, int nch, int runs, int hop, double *Sl) {
-    hipLaunchKernelGGL(k_cm_blocksums, dim3((hop + 255) / 256, nch), dim3(256), 0, c.stream, spartial, runs, hop, Sl);
+    hipLaunchKernelGGL(k_cm_blocksums, dim3((hop + 15) / 16, nch), dim3(256), 0, c.stream, spartial, runs, hop, Sl);
     return 0;
 }
 // Xs: pair-interleaved spectra [nch][npairs][ld][2] of m frames (the second frame of an odd last pair is zero)

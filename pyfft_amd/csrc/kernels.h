@@ -1717,6 +1717,7 @@ static __global__ void k_colsum_real(const float *__restrict__ x, const float *_
     const int64_t per = (M + gridDim.y - 1) / gridDim.y;
     const int64_t b0 = 1 + (int64_t)blockIdx.y * per, b1 = b0 + per < M + 1 ? b0 + per : M + 1;
     double a = 0.0;
+#pragma unroll 8
     for (int64_t b = b0; b < b1; ++b) a += (double)(x[b * H + j] - mu);
     out[(int64_t)blockIdx.y * H + j] = mk((float)a, 0.f);
 }

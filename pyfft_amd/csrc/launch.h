@@ -164,7 +164,7 @@ int launch_csd_pair(LaunchCtx c, const float *y, int nch, int64_t y_ld, const fl
 int launch_csd_pair_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int nch, int sided, double scale,
                            double *pyy, double *pxy, const double *st_y = nullptr, const double *st_x = nullptr, const cf *Wf = nullptr,
                            const float *trend_x = nullptr, const float *trend_y = nullptr, int64_t nmean = 0, int64_t M = 0);
-#define SP_COLSUM_SLICES 64
+#define SP_COLSUM_SLICES 256
 int launch_colsum_real(LaunchCtx c, const float *x, const float *trend, int H, int64_t M, cf *out);
 int launch_csdm_transpose(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int64_t mc, int nb);
 int launch_csdm_gemm(LaunchCtx c, const cf *Xt, int nch, int64_t mc, int nb, double *G);

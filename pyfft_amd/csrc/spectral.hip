@@ -1142,8 +1142,10 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
     // (k_welch_csd_pair<OP>: estimate + block sums, exact correction in k_csd_pair_finish); SP_CSD_TWOPASS=1: the separate pass
     const bool pair_path = !lng && !cplx && !segmean && csd_rp_eligible(xf) && nch >= 2 && nframes >= 2 && !env_flag("SP_NO_REALPAIR") &&
                            !env_flag("SP_CSD_XIY");
+    // (from 8 channels on: below, the epilogue's fixed ~0.1 ms costs more than the channels' pass, 0.39 against 0.35 ms at 2 channels
+    //  x 2^24, 0.55 / 0.56 at 8, 0.76 / 0.83 at 16; SP_CSD_ONEPASS=1 forces the form)
     const bool pair_op = pair_path && detrend == SP_DETREND_MEAN && xf.L == 4096 && 2 * hop == xf.L && nch <= 512 &&
-                         !env_flag("SP_CSD_TWOPASS");
+                         (nch >= 8 || env_flag("SP_CSD_ONEPASS")) && !env_flag("SP_CSD_TWOPASS");
     if (pair_op) {
         HIPCHK(hipMemsetAsync(tb.f + 4, 0, sizeof(float) * 4 * (size_t)nch, g.stream));     // (the kernel publishes its estimates here)
     } else if (detrend != 0 && nch <= 512) {

@@ -738,7 +738,7 @@ def test_welch_csd_reference_once_path(E, nfft, hop, n, nch, detrend, monkeypatc
         assert np.max(np.abs(v - w)) <= 3e-5 * np.abs(w).max()
 
 
-@pytest.mark.parametrize("M,tail,nch", [(301, 0, 5), (300, 777, 3), (2051, 5000, 2)])
+@pytest.mark.parametrize("M,tail,nch", [(301, 0, 5), (300, 777, 3), (2051, 5000, 2), (301, 100, 9)])
 def test_welch_csd_reference_once_one_pass_means(E, M, tail, nch, monkeypatch):
     """reference against >= 2 real channels at nfft 4096 / 50 % overlap with mean detrend: the channels' means are taken in the
     pass that forms the spectra (estimate + block sums + exact correction in the finish kernel).  Against the separate mean
@@ -751,6 +751,8 @@ def test_welch_csd_reference_once_one_pass_means(E, M, tail, nch, monkeypatch):
     x = (np.sin(0.11 * k) + 0.3 * rng.standard_normal(n) - 0.4).astype(np.float32)
     y = np.stack([0.5 * np.sin(0.11 * k + 0.3 * c) + 0.2 * rng.standard_normal(n) + 1.5 * (c + 1) for c in range(nch)]).astype(np.float32)
     win = O.windows("Hanning", nwins=nfft)
+    if nch < 8:
+        monkeypatch.setenv("SP_CSD_ONEPASS", "1")          # (the default takes the form from 8 channels on)
     for sided in (E.SIDED_TWO, E.SIDED_ONE, E.SIDED_RAW):
         a = E.welch_csd(x, y, win, hop, M, detrend=True, sided=sided, scale=1.0)
         monkeypatch.setenv("SP_CSD_TWOPASS", "1")
