@@ -17,7 +17,7 @@
 
 using namespace sp;
 
-#define SP_VERSION 103
+#define SP_VERSION 104
 #define SP_MAX_WG_FFT 8192
 #define SP_MAX_BIG_LOG2 26          /* longest multi-pass power-of-two transform: 2^26 points (512 MiB per buffer) */
 
@@ -1361,7 +1361,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     };
     // mean detrend in ONE pass over the signals (single chunk): the spectra stage subtracts an estimate mu0 of every channel's
     // mean and leaves its block sums; the exact means and B_i = sum_g X_i,g follow from them (k_op_finish per channel) and the
-    // matrix is corrected at the end (k_cm_correct).  Saves the separate pass over all samples for the means
+    // matrix is corrected at the end (in k_csdm_fold).  Saves the separate pass over all samples for the means
     const bool cm_onepass = detrend == 1 && !means_host && nframes <= mc && pipe_spec(nframes) && !env_flag("SP_CSDM_TWOPASS");
     if (cm_onepass) {
         HIPCHK(hipMemsetAsync(tb.f, 0, sizeof(float) * 4 * (size_t)nch, g.stream));   // (the spectra stage estimates and publishes mu0)
