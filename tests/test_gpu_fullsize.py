@@ -195,6 +195,14 @@ def test_cfg5_csd_matrix_full_size(T, E):
     got = G[:, 40, 3].cpu().numpy()
     ref = pxy[0][: nfft // 2 + 1].cpu().numpy()
     assert np.max(np.abs(got - ref)) <= 2e-4 * np.abs(ref).max()
+    # 16 channels against channel 0: the reference-once pair kernels with the channels' means taken in the same pass (from 8
+    # channels on) -- an independent route to the same matrix entries
+    pxx, pyy, pxy = E.welch_csd(x[0], x[1:17], win, hop, M, detrend=True, sided=E.SIDED_RAW, scale=1.0)
+    for c in (0, 7, 15):
+        got = G[:, c + 1, 0].cpu().numpy()
+        ref = pxy[c][: nfft // 2 + 1].cpu().numpy()
+        assert np.max(np.abs(got - ref)) <= 2e-4 * np.abs(ref).max(), c
+        np.testing.assert_allclose(pyy[c][: nfft // 2 + 1].cpu().numpy(), G[:, c + 1, c + 1].real.cpu().numpy(), rtol=2e-4)
     coh = (G[:, 3, 40].abs() ** 2 / (G[:, 3, 3].real * G[:, 40, 40].real)).cpu().numpy()
     coh_null = (G[:, 3, 41].abs() ** 2 / (G[:, 3, 3].real * G[:, 41, 41].real)).cpu().numpy()
     assert np.median(coh[10:-10]) > 0.1 and np.median(coh_null[10:-10]) < 1e-3
