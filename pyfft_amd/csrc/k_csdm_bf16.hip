@@ -357,7 +357,10 @@ static __global__ __launch_bounds__(512) void k_csdm_bf16(const cf *__restrict__
             const int i = 32 * bi + 8 * (v / 4) + 4 * half + (v % 4), j = 32 * bj + col;
             if (i < nch && j < nch) {
                 double *p = G + (((int64_t)k * nch + i) * nch + j) * 2;
-                if (atomic) {
+                if (atomic == 2) {                 // first contribution of an unsliced unit: store (G need not be zeroed)
+                    p[0] = (double)accR[b][v];
+                    p[1] = (double)accI[b][v];
+                } else if (atomic) {
                     atomicAdd(p, (double)accR[b][v]);
                     atomicAdd(p + 1, (double)accI[b][v]);
                 } else {
@@ -389,9 +392,12 @@ static __global__ void k_csdm_gather_bins_pi(const cf *__restrict__ Xs, cf *__re
 // The spectra were detrended by the estimates mu0_i; with d_i = mean_i - mu0_i (real), W = FFT(window), B_i = sum_g X_i,g:
 //   sum_g (X_i - d_i W) conj(X_j - d_j W) = G_ij - d_j conj(W) B_i - d_i W conj(B_j) + M d_i d_j |W|^2
 // st[ch] = state of k_op_finish<EXPORT>: B at [n .. 3n), the channel's plain sample sum at 5n + 3; nmean samples per channel
+// init: G holds nothing yet (every chunk went through H): the result is STORED, scaled, and mirrored into the blocks below the
+// diagonal blocks in the same sweep (k_csdm_finish / k_csdm_mirror and the zeroing of G are then not needed)
 static __global__ __launch_bounds__(256) void k_csdm_fold(const double *__restrict__ H, double *__restrict__ G, int nch, int n,
                                                           const double *__restrict__ st, const cf *__restrict__ Wf,
-                                                          const float *__restrict__ trend, int64_t nmean, int64_t M) {
+                                                          const float *__restrict__ trend, int64_t nmean, int64_t M, double scale,
+                                                          int init) {
     __shared__ double sd[64], sbr[64], sbi[64];
     const int64_t per = (int64_t)nch * nch;
     const int k = blockIdx.x;
@@ -415,7 +421,7 @@ static __global__ __launch_bounds__(256) void k_csdm_fold(const double *__restri
         if (j / 32 < i / 32) continue;
         const double2 a = reinterpret_cast<const double2 *>(H)[k * per + ij];
         const double2 b = reinterpret_cast<const double2 *>(H)[km * per + ij];
-        double2 gv = reinterpret_cast<double2 *>(G)[k * per + ij];
+        double2 gv = init ? make_double2(0.0, 0.0) : reinterpret_cast<double2 *>(G)[k * per + ij];
         gv.x += 0.5 * (a.x + b.x);
         gv.y += 0.5 * (a.y - b.y);
         if (st) {
@@ -423,13 +429,18 @@ static __global__ __launch_bounds__(256) void k_csdm_fold(const double *__restri
             gv.x += -dj * (wr * sbr[i] + wi * sbi[i]) - di * (wr * sbr[j] + wi * sbi[j]) + mw * di * dj;
             gv.y += -dj * (wr * sbi[i] - wi * sbr[i]) - di * (wi * sbr[j] - wr * sbi[j]);
         }
+        if (init) {
+            gv.x *= scale;
+            gv.y *= scale;
+            if (j / 32 > i / 32) reinterpret_cast<double2 *>(G)[k * per + (int64_t)j * nch + i] = make_double2(gv.x, -gv.y);
+        }
         reinterpret_cast<double2 *>(G)[k * per + ij] = gv;
     }
 }
 int launch_csdm_fold(LaunchCtx c, const double *H, double *G, int nch, int n, const double *st, const cf *Wf, const float *trend,
-                     int64_t nmean, int64_t M) {
+                     int64_t nmean, int64_t M, double scale, int init) {
     if (nch > 64) return -1;
-    hipLaunchKernelGGL(k_csdm_fold, dim3(n / 2 + 1), dim3(256), 0, c.stream, H, G, nch, n, st, Wf, trend, nmean, M);
+    hipLaunchKernelGGL(k_csdm_fold, dim3(n / 2 + 1), dim3(256), 0, c.stream, H, G, nch, n, st, Wf, trend, nmean, M, scale, init);
     return 0;
 }
 
@@ -471,7 +482,8 @@ int launch_cm_blocksums(LaunchCtx c, const cf *spartial, int nch, int runs, int 
 }
 // Xs: pair-interleaved spectra [nch][npairs][ld][2] of m frames (the second frame of an odd last pair is zero)
 // (Xs may also hold PACKED pair spectra with `m` pairs as frames and nb = nfft bins: see k_csdm_fold)
-int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld, int two_pieces) {
+// init: G holds nothing yet -- an unsliced launch without tail bins stores its sums, otherwise G is zeroed here first
+int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld, int two_pieces, int init) {
     if (nch > 64 || ld < nb || (ld % CB_BINS) != 0) return -1;
     const int64_t npairs = (m + 1) / 2;
     const int nchp = 64;
@@ -493,12 +505,17 @@ int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m,
                 return -1;
             attr_done = true;
         }
+        int mode = slices > 1 ? 1 : 0;
+        if (init) {
+            if (slices == 1 && nb == CB_BINS * ngroups) mode = 2;
+            else if (hipMemsetAsync(G, 0, sizeof(double) * 2 * (size_t)nb * (size_t)nch * (size_t)nch, c.stream) != hipSuccess) return -1;
+        }
         if (two_pieces)
             hipLaunchKernelGGL(k_csdm_bf16<4>, dim3(ngroups * slices), dim3(512), lds, c.stream, Xs, nch, npairs, ld, ngroups, G, ps,
-                               slices, slices > 1);
+                               slices, mode);
         else
             hipLaunchKernelGGL(k_csdm_bf16<0>, dim3(ngroups * slices), dim3(512), lds, c.stream, Xs, nch, npairs, ld, ngroups, G, ps,
-                               slices, slices > 1);
+                               slices, mode);
     }
     const int kfirst = CB_BINS * ngroups, ntail = nb - kfirst;
     if (ntail > 0) {

@@ -171,9 +171,9 @@ int launch_csdm_gemm(LaunchCtx c, const cf *Xt, int nch, int64_t mc, int nb, dou
 int launch_csdm_finish(LaunchCtx c, double *G, int nch, int nb, double scale, int blk);
 int launch_csdm_transpose_kgc(LaunchCtx c, const cf *Xs, cf *Xt, int nch, int nchp, int64_t m, int64_t mp, int nb);
 int launch_csdm_mfma(LaunchCtx c, const cf *Xt, int nch, int nchp, int64_t mp, int nb, double *G);
-int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld, int two_pieces = 0);
+int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld, int two_pieces = 0, int init = 0);
 int launch_csdm_fold(LaunchCtx c, const double *H, double *G, int nch, int n, const double *st = nullptr, const cf *Wf = nullptr,
-                     const float *trend = nullptr, int64_t nmean = 0, int64_t M = 0);
+                     const float *trend = nullptr, int64_t nmean = 0, int64_t M = 0, double scale = 1.0, int init = 0);
 int launch_cm_blocksums(LaunchCtx c, const cf *spartial, int nch, int runs, int hop, double *Sl);
 int launch_op_finish_channels(LaunchCtx c, const float *x, int64_t x_cs, int nch, const float *trend, const float *win,
                               const double *Sl, const cf *Wf, int hop, int64_t nframes, int64_t nmean, const Xf &xf, double *out);

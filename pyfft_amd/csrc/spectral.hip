@@ -1312,7 +1312,9 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
         if (g.cmG.ensure(gbytes)) return -1;
         G = (double *)g.cmG.p;
     }
-    HIPCHK(hipMemsetAsync(G, 0, gbytes, g.stream));
+    // (G is zeroed lazily, by the first chunk that adds into it directly: a call whose chunks all go through the packed spectra
+    //  never needs it -- k_csdm_fold then stores, scales and mirrors in its one sweep)
+    bool g_zeroed = false;
     // frames are processed in chunks so the two spectra buffers stay <= 8 GiB each (and float sums stay short)
     int64_t mc = ((int64_t)1 << 31) / ((int64_t)nch * nb);     // <= 16 GiB per spectra buffer
     if (mc > 16384) mc = 16384;
@@ -1412,7 +1414,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
             const size_t hbytes = sizeof(double) * 2 * (size_t)nfft * (size_t)nch * (size_t)nch;
             if (g.cmS.ensure(zbytes) || g.cmH.ensure(hbytes)) return -1;
             Xs = (cf *)g.cmS.p;
-            if (!fold_pending) HIPCHK(hipMemsetAsync(g.cmH.p, 0, hbytes, g.stream));
+            const int h_init = fold_pending ? 0 : 1;             // first chunk: H is initialised by the contraction itself
             fold_pending = true;
             cf *spartial = nullptr;
             if (cm_onepass) {
@@ -1425,7 +1427,7 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
             }
             LAUNCHCHK(launch_welch_pipe(lc(), xd + (size_t)f0 * (size_t)hop, false, (const float *)win_d, hop, m, tb.f + 4 * nch, xf,
                                         (float *)Xs, rp, spartial, 5, nch, x_ld, nfft / 8));
-            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, pairs, nfft, (double *)g.cmH.p, nfft, split2));
+            LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, pairs, nfft, (double *)g.cmH.p, nfft, split2, h_init));
             continue;
         } else if (use_bf16) {
             const RunPart rp = run_partition_2d(xf.L, (m + 1) / 2, g.ncu, nch);
@@ -1448,6 +1450,10 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
                                       (const float *)win_d, hop, m, tb.f + 4 * (nch + c), detrend == 2, xf, rp, SP_SIDED_HALF,
                                       1.f, 0, Xs + (size_t)c * (size_t)m * (size_t)nb, nullptr));
         }
+        if (!g_zeroed) {
+            HIPCHK(hipMemsetAsync(G, 0, gbytes, g.stream));
+            g_zeroed = true;
+        }
         if (use_bf16) {
             LAUNCHCHK(launch_csdm_bf16(lc(), Xs, Xt, nch, m, nb, G, ld, split2));
         } else if (use_fused) {
@@ -1461,6 +1467,8 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
             LAUNCHCHK(launch_csdm_gemm(lc(), Xt, nch, m, nb, G));
         }
     }
+    const double gscale = scale / (double)nframes;
+    const int fold_init = (fold_pending && !g_zeroed) ? 1 : 0;          // nothing was added into G directly: the fold finishes G
     if (cm_onepass) {
         void *Wf_d;
         if (get_window_spectrum(win, nfft, xf, &Wf_d)) return -1;
@@ -1468,11 +1476,12 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
         LAUNCHCHK(launch_cm_blocksums(lc(), (const cf *)g.cmO.p, nch, op_runs, hop, Sl));
         LAUNCHCHK(launch_op_finish_channels(lc(), xd, x_ld, nch, tb.f + 4 * nch, (const float *)win_d, Sl, (const cf *)Wf_d, hop,
                                             nframes, nsig, xf, st));
-        LAUNCHCHK(launch_csdm_fold(lc(), (const double *)g.cmH.p, G, nch, nfft, st, (const cf *)Wf_d, tb.f + 4 * nch, nsig, nframes));
+        LAUNCHCHK(launch_csdm_fold(lc(), (const double *)g.cmH.p, G, nch, nfft, st, (const cf *)Wf_d, tb.f + 4 * nch, nsig, nframes,
+                                   gscale, fold_init));
     } else if (fold_pending) {
-        LAUNCHCHK(launch_csdm_fold(lc(), (const double *)g.cmH.p, G, nch, nfft));
+        LAUNCHCHK(launch_csdm_fold(lc(), (const double *)g.cmH.p, G, nch, nfft, nullptr, nullptr, nullptr, 0, 0, gscale, fold_init));
     }
-    LAUNCHCHK(launch_csdm_finish(lc(), G, nch, nb, scale / (double)nframes, use_mfma ? 32 : SP_CM_B));
+    if (!fold_init) LAUNCHCHK(launch_csdm_finish(lc(), G, nch, nb, gscale, use_mfma ? 32 : SP_CM_B));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(g_out, G, gbytes, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
