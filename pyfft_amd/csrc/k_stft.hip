@@ -60,6 +60,12 @@ int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64
     return 0;
 }
 
+int launch_cog_finish_op(LaunchCtx c, const cf *acc, int wpf, int64_t nframes, double df, double *out, const cf *lobe, CogLobe lb,
+                         const double *st, const float *trend, int64_t nmean, int n) {
+    hipLaunchKernelGGL(k_cog_finish_op, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, c.stream, acc, wpf, nframes, df, out,
+                       lobe, lb, st, trend, nmean, n);
+    return 0;
+}
 int launch_cog_finish(LaunchCtx c, const cf *acc, int wpf, int64_t nframes, double df, double *out) {
     hipLaunchKernelGGL(k_cog_finish, dim3((unsigned)((nframes + 255) / 256)), dim3(256), 0, c.stream, acc, wpf, nframes, df, out);
     return 0;

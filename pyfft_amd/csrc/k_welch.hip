@@ -218,12 +218,19 @@ int launch_op_apply(LaunchCtx c, const double *state, const cf *Wf, int n, int s
 // one-pass mean detrend of MANY real channels (the CSD matrix on packed pair spectra): per channel, from the block sums Sl and
 // the mean estimate in its trend record, the state of k_op_finish<EXPORT>: B = sum_g X_g, the plain sample sum, ... (5 L + 8
 // doubles per channel)
-int launch_op_finish_channels(LaunchCtx c, const float *x, int64_t x_cs, int nch, const float *trend, const float *win,
-                              const double *Sl, const cf *Wf, int hop, int64_t nframes, int64_t nmean, const Xf &xf, double *out) {
+int launch_op_finish_channels(LaunchCtx c, const void *x, int64_t x_cs, int nch, const float *trend, const float *win,
+                              const double *Sl, const cf *Wf, int hop, int64_t nframes, int64_t nmean, const Xf &xf, double *out,
+                              bool cplx) {
     if (xf.L != 4096) return -1;
     const int H = hop, r = xf.L / H;
+    if (cplx) {
+        hipLaunchKernelGGL((k_op_finish<4096, true, true>), dim3(nch), dim3(WgCfg<4096>::WG), WgCfg<4096>::lds_bytes(1), c.stream, x,
+                           trend, win, Sl, Sl, Wf, (const double *)nullptr, (const double *)nullptr, H, r, nframes, nmean, 2, 1.0, xf.tb,
+                           out, 0, x_cs, (int64_t)2 * H, (int64_t)5 * xf.L + 8);
+        return 0;
+    }
     hipLaunchKernelGGL((k_op_finish<4096, false, true>), dim3(nch), dim3(WgCfg<4096>::WG), WgCfg<4096>::lds_bytes(1), c.stream,
-                       (const void *)x, trend, win, Sl, Sl /* A: unused by the consumers of this state */, Wf, (const double *)nullptr,
+                       x, trend, win, Sl, Sl /* A: unused by the consumers of this state */, Wf, (const double *)nullptr,
                        (const double *)nullptr, H, r, nframes, nmean, 2, 1.0, xf.tb, out, 0, x_cs, (int64_t)2 * H,
                        (int64_t)5 * xf.L + 8);
     return 0;

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
                                                      int64_t nframes, int64_t fpg, float *__restrict__ trend_in, XfTables tb,
                                                      float *__restrict__ partial, cf *__restrict__ spartial, int64_t x_cs, int gpr) {
     constexpr int N = 4096;
-    constexpr bool RP = MODE >= 3;           // real input, two frames per transform (modes 3: plain, 4: one-pass detrend, 5: spectra)
-    constexpr bool ONEPASS = MODE == 1 || MODE == 4 || MODE == 7, COG = MODE == 2;          // (7: mode 5 with the one-pass block sums)
+    constexpr bool RP = MODE >= 3 && MODE != 8;         // real input, two frames per transform (modes 3: plain, 4: one-pass detrend, 5: spectra)
+    constexpr bool ONEPASS = MODE == 1 || MODE == 4 || MODE == 7 || MODE == 8, COG = MODE == 2 || MODE == 8;   // (7: mode 5, 8: mode 2, with the one-pass block sums)
     // mode 5: no accumulation -- the packed pair spectrum Z = X_2q + i X_2q+1 of every frame pair is WRITTEN, all N bins, for the
     // CSD-matrix contraction: Zs[pair of pairs][group of 8 bins][channel slot of 64][8 bins][2 pairs] (k_csdm_bf16's layout with
     // "frames" = pairs).  The contraction of the PACKED spectra, H[k] = sum Z_i[k] conj Z_j[k], gives the matrix by the mirror
@@ -444,6 +444,16 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
                         }
                     }
                 } else if constexpr (COG) {
+                    if constexpr (MODE == 8) {
+                        // one-pass mean detrend of a cosine-sum window: the bins ks = -3 .. 3 of every frame go to lobe[frame][ks + 3]
+                        // (behind the slot array); k_cog_finish corrects the moments there with the exact mean
+                        const int64_t gf = g0 + (p - 4);
+                        cf *lobe = reinterpret_cast<cf *>(partial) + 4 * nframes + gf * 8;
+                        if (gf < nframes) {
+                            if (tid <= 3) lobe[3 + tid] = use[0];
+                            if (tid >= T - 3) lobe[3 - (T - tid)] = use[R - 1];
+                        }
+                    }
                     // ks = tid + c_t with c_t = T t - (N in the upper half): sum ks p = tid sum p + sum c_t p
                     float numc = 0.f, den = 0.f;
 #pragma unroll
@@ -529,6 +539,11 @@ int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, i
     } else if (mode == 3) {
         if (cplx || shift != 8) return -1;
         if (spartial) PIPE_(false, 8, 4) else PIPE_(false, 8, 3)
+    } else if (mode == 2 && spartial) {
+        // moments per frame with the one-pass mean detrend (mode 8): hop 2048 / 1024 only (16 new slots per thread spill)
+        if (shift == 8) { if (cplx) PIPE_(true, 8, 8) else PIPE_(false, 8, 8) }
+        else if (shift == 4) { if (cplx) PIPE_(true, 4, 8) else PIPE_(false, 4, 8) }
+        else return -1;
     } else if (mode == 2) {
         if (cplx) { PIPE_S_(true, 2) } else { PIPE_S_(false, 2) }
     } else if (spartial) {

@@ -1960,6 +1960,37 @@ static __global__ void k_cog_finish(const cf *__restrict__ acc, int wpf, int64_t
     out[g] = den > 0.0 ? df * num / den : 0.0;
 }
 
+// bins ks = -K .. K of FFT(window) (float64, from the host), K <= 3: the lobe of a cosine-sum window
+struct CogLobe {
+    int K;
+    double wr[7], wi[7];
+};
+// the same with the one-pass mean detrend of a cosine-sum window (k_welch_pipe mode 8): the spectra were detrended by the estimate
+// mu0; with d = mean - mu0 (st: state of k_op_finish<EXPORT>, plain sample sums at 5n + 3, 5n + 4) and W = FFT(window), non-zero
+// in the bins ks = -K .. K only, |X - d W|^2 - |X|^2 = -2 Re(conj(d W) X) + |d W|^2 there: 2K + 1 terms per frame from lobe[g][ks + 3]
+static __global__ void k_cog_finish_op(const cf *__restrict__ acc, int wpf, int64_t nframes, double df, double *__restrict__ out,
+                                       const cf *__restrict__ lobe, CogLobe lb, const double *__restrict__ st,
+                                       const float *__restrict__ trend, int64_t nmean, int n) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nframes) return;
+    double num = 0.0, den = 0.0;
+    for (int w = 0; w < wpf; ++w) {
+        const cf a = acc[(int64_t)w * nframes + g];
+        num += (double)a.x;
+        den += (double)a.y;
+    }
+    const double dr = st[5 * n + 3] / (double)nmean - (double)trend[0], di = st[5 * n + 4] / (double)nmean - (double)trend[1];
+    for (int ks = -lb.K; ks <= lb.K; ++ks) {
+        const double wr = lb.wr[ks + 3], wi = lb.wi[ks + 3];
+        const double er = dr * wr - di * wi, ei = dr * wi + di * wr;             // d W
+        const cf x = lobe[g * 8 + ks + 3];
+        const double dp = -2.0 * (er * (double)x.x + ei * (double)x.y) + er * er + ei * ei;
+        den += dp;
+        num += (double)ks * dp;
+    }
+    out[g] = den > 0.0 ? df * num / den : 0.0;
+}
+
 // Real input STFT, two frames per transform: z = f_g + i f_{g+1};  X_g = (Z[k] + conj Z[n-k]) / 2,
 // X_{g+1} = (Z[k] - conj Z[n-k]) / (2i).  The mirror comes from one more LDS exchange (linear image, reversed read).
 // Power-of-two n only (mirror index by masking); the other lengths use k_stft.

@@ -175,8 +175,11 @@ int launch_csdm_bf16(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m,
 int launch_csdm_fold(LaunchCtx c, const double *H, double *G, int nch, int n, const double *st = nullptr, const cf *Wf = nullptr,
                      const float *trend = nullptr, int64_t nmean = 0, int64_t M = 0, double scale = 1.0, int init = 0);
 int launch_cm_blocksums(LaunchCtx c, const cf *spartial, int nch, int runs, int hop, double *Sl);
-int launch_op_finish_channels(LaunchCtx c, const float *x, int64_t x_cs, int nch, const float *trend, const float *win,
-                              const double *Sl, const cf *Wf, int hop, int64_t nframes, int64_t nmean, const Xf &xf, double *out);
+int launch_op_finish_channels(LaunchCtx c, const void *x, int64_t x_cs, int nch, const float *trend, const float *win,
+                              const double *Sl, const cf *Wf, int hop, int64_t nframes, int64_t nmean, const Xf &xf, double *out,
+                              bool cplx = false);
+int launch_cog_finish_op(LaunchCtx c, const cf *acc, int wpf, int64_t nframes, double df, double *out, const cf *lobe, CogLobe lb,
+                         const double *st, const float *trend, int64_t nmean, int n);
 int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld = 0);
 int launch_hilbert_mid(LaunchCtx c, cf *Z, int64_t M, BigTw bt);
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out,

@@ -773,6 +773,43 @@ def test_welch_csd_reference_once_one_pass_means(E, M, tail, nch, monkeypatch):
         assert np.max(np.abs(pxy[c] - rxy)) <= 2e-5 * np.abs(rxy).max()
 
 
+@pytest.mark.parametrize("hop,cplx,wname", [(2048, True, "Hanning"), (1024, True, "Hamming"), (2048, False, "Hanning")])
+def test_cog_one_pass_mean_detrend(E, hop, cplx, wname, monkeypatch):
+    """Centre of gravity per frame with mean detrend, nfft 4096: for a cosine-sum window the mean is not taken by a pass of its
+    own -- the kernel detrends by an estimate, keeps the 7 lowest bins of every frame and k_cog_finish_op corrects the moments
+    with the exact mean.  Against the separate mean pass (SP_COG_TWOPASS=1) and numpy float64 on sampled frames; a DC offset
+    far above the signal (it would drag every centre of gravity to zero if mishandled)"""
+    nfft, M, fs = 4096, 9000, 1000.0
+    n = (M - 1) * hop + nfft + 333
+    rng = np.random.default_rng(hop + int(cplx))
+    t = np.arange(n)
+    ph = 2 * np.pi * (0.11 * t + 0.04 * n / (2 * np.pi * 3) * np.sin(2 * np.pi * 3 * t / n))
+    if cplx:
+        x = (np.exp(1j * ph) + 0.3 * (rng.standard_normal(n) + 1j * rng.standard_normal(n)) + (2.0 - 1.5j)).astype(np.complex64)
+    else:
+        x = (np.cos(ph) + 0.3 * rng.standard_normal(n) + 2.5).astype(np.float32)
+    win = O.windows(wname, nwins=nfft)
+    a = E.stft_cog(x, win, hop, M, fs, detrend=True)
+    monkeypatch.setenv("SP_COG_TWOPASS", "1")
+    b = E.stft_cog(x, win, hop, M, fs, detrend=True)
+    monkeypatch.delenv("SP_COG_TWOPASS")
+    assert np.max(np.abs(a - b)) > 0                      # (two different paths ran)
+    assert np.max(np.abs(a - b)) <= 2e-5 * fs
+    x64 = x.astype(np.complex128 if cplx else np.float64)
+    x64 = x64 - x64.mean()
+    ks = np.fft.fftfreq(nfft, 1.0 / nfft)
+    for g in range(0, M, 997):
+        P = np.abs(np.fft.fft(win * x64[g * hop:g * hop + nfft])) ** 2
+        ref = fs / nfft * np.sum(ks * P) / np.sum(P)
+        assert abs(a[g] - ref) <= 2e-5 * fs, (g, a[g], ref)
+    # a window whose spectrum is not confined to a few bins keeps the separate pass
+    wk = np.kaiser(nfft, 8.0)
+    c = E.stft_cog(x, wk, hop, M, fs, detrend=True)
+    monkeypatch.setenv("SP_COG_TWOPASS", "1")
+    d = E.stft_cog(x, wk, hop, M, fs, detrend=True)
+    assert np.array_equal(c, d)
+
+
 # ---------------------------------------------------------------- A6 / N1 epilogue on device-resident spectra
 @pytest.mark.parametrize("nfft,onesided", [(1024, True), (1333, True), (512, False), (777, False)])
 def test_csd_epilogue_on_device(E, nfft, onesided):
