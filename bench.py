@@ -7,17 +7,23 @@
                                                           torch.distributed.run before anything touches a GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over one batch of synthetic input: every rank runs the fused Welch PSD
-(global-mean detrend + window + overlapped FFT + |X|^2 + segment average, one pass over the samples) over its own
-2^28-sample segment of the stream, device-resident; at N>1 the shards' additive states (|X|^2 accumulator + what is
-needed to apply the mean of the whole stream: 5*4096+8 doubles) are summed with ONE RCCL all-reduce (the only
-exchange the path has), issued asynchronously so that it overlaps the kernels of the next step (pyfft_amd.dist.
-WelchPipeline; the timed region holds K submits and the final flush = exactly K steps of work).  Weak scaling: per-GPU
-work is fixed, value = all samples / max-over-ranks time.
+A "step" = one pass of the hot path over one batch of synthetic input: the fused Welch PSD (global-mean detrend + window
++ overlapped FFT + |X|^2 + segment average, one pass over the samples) of ONE 2^28-sample complex64 stream, device-resident.
+At N > 1 the stream is split N ways by frames (pyfft_amd.dist.shard_plan: contiguous frame ranges + a 2048-sample halo) --
+STRONG scaling, the configuration BASELINE.json's metric names ("a 2^28-sample complex64 stream at 1, 2, 4 and 8 GPUs") and
+the headline `value`; the shards' additive states (|X|^2 accumulator + what is needed to apply the mean of the WHOLE stream:
+5*4096+8 doubles) are summed with ONE RCCL all-reduce per step (the only exchange the path has), issued asynchronously so
+that it overlaps the kernels of the next step (pyfft_amd.dist.WelchPipeline; the timed region holds K submits and the final
+flush = exactly K steps of work).  The weak-scaling figure (2^28 samples per GPU) is measured in the same run and reported
+under "weak_scaling".  The stream is counter-based (synth.py: splitmix64(seed ^ k) -> Box-Muller + two tones), so every
+rank generates exactly its own samples of the same stream and results are comparable across N: at N > 1 rank 0 gates the
+timed result against one GPU's PSD of the whole stream and a 2^22-sample prefix through the same sharded path against the
+CPU oracle.
 
-Prints ONE JSON line on rank 0.  Extra objects: roofline (dominant kernel k_welch, HIP events on the launch
+Prints ONE JSON line on rank 0.  Extra objects: roofline (dominant kernel k_welch_pipe, HIP events on the launch
 stream; traffic from the PMC record of THIS build under profiles/, else null), cpu_baseline (the CPU oracle
 `welch_psd_stream` on the host cores, bounded sample: all usable cores and one core; N=1 only).
+SP_BENCH_FORCE_DIST=1 (with --gpus 1): the sharded code path with an RCCL process group of one rank.
 """
 import argparse
 import hashlib
@@ -36,7 +42,8 @@ sys.path.insert(0, ROOT)
 
 from pyfft_amd import engine as E          # noqa: E402
 from pyfft_amd.windows import windows      # noqa: E402
-from pyfft_amd.dist import shard_plan, WelchPipeline   # noqa: E402
+from pyfft_amd.dist import shard_plan, WelchPipeline, NativeWelchPipeline, native_comm_init   # noqa: E402
+import synth                              # noqa: E402
 
 HBM_PEAK_GBS = 8000.0                      # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 PMC_RECORD = os.path.join(ROOT, "profiles", "pmc_metric_kernel_current.json")
@@ -85,125 +92,53 @@ def self_launch(ngpus):
     return subprocess.run(cmd, env=env).returncode
 
 
-def synth_stream(n0, n, device, seed):
-    """complex64 samples [n0, n0+n) of the synthetic stream: unit-variance complex white
-    noise + the two Heinzel section-13 tones at fs = 1.  Noise comes from torch's device generator seeded per
-    segment; phases are evaluated in float64."""
-    gen = torch.Generator(device=device)
-    gen.manual_seed(seed)
-    out = torch.empty(n, dtype=torch.complex64, device=device)
-    chunk = 1 << 24
-    for a in range(0, n, chunk):
-        b = min(n, a + chunk)
-        k = torch.arange(n0 + a, n0 + b, dtype=torch.float64, device=device)
-        noise = torch.randn((b - a, 2), generator=gen, dtype=torch.float32, device=device) * (0.5 ** 0.5)
-        z = torch.view_as_complex(noise).to(torch.complex128)
-        z = z + 2.82842712 * torch.exp(2j * np.pi * torch.remainder(0.1234 * k, 1.0))
-        z = z + 1.0 * torch.exp(2j * np.pi * torch.remainder(0.25002157 * k, 1.0))
-        z = z + (0.05 - 0.02j)                       # a small offset so the detrend has something to remove
-        out[a:b] = z.to(torch.complex64)
-    return out
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--settle-steps", type=int, default=60,
-                    help="untimed steps before the warm-up steps so that the GPU clocks have ramped: the first ~40 "
-                         "steps after idle run 10-25 %% slower (tools/steptrace.py).  A fixed count, not a time, so "
-                         "that every rank issues the same collectives.  0 = off")
-    ap.add_argument("--log2n", type=int, default=28, help="samples per GPU = 2^log2n")
-    ap.add_argument("--nfft", type=int, default=4096)
-    ap.add_argument("--cpu-log2n", type=int, default=28, help="CPU-baseline sample = first 2^k samples (0 = skip)")
-    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the all-cores CPU baseline "
-                                                             "(0 = the cores this process may run on, at most 32)")
-    args = ap.parse_args()
-
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        raise SystemExit(self_launch(args.gpus))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    if os.environ.get("SP_BENCH_DRYRUN", "") not in ("", "0"):
-        # launch-plumbing rehearsal for machines without a GPU (tests/test_dist_cpu.py): rendezvous over gloo, one
-        # all-reduce, one JSON line from rank 0 -- no kernels, not a measurement
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(free_port()))
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
-        dist.all_reduce(t)
-        if rank == 0:
-            print(json.dumps({"dryrun": True, "n_gpus": world, "rank_sum": float(t.item()), "steps": args.steps}))
-        dist.destroy_process_group()
-        return
-    dist = None
-    # rehearsal on a one-GPU box: SP_BENCH_ONE_GPU=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
-    # ranks on one device); the driver's real runs use one GPU per rank over RCCL
-    one_gpu = os.environ.get("SP_BENCH_ONE_GPU", "") not in ("", "0")
-    if one_gpu:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    nfft = args.nfft
-    hop = nfft // 2
-    S = 1 << args.log2n                                  # samples per GPU (weak scaling)
-    total = S * world                                    # whole stream
-    plan = shard_plan(total, nfft, hop, world, rank)     # contiguous frame ranges + (nfft-hop)-sample halo
-    M_total, M_local, n_local = plan.frames_total, plan.frames, plan.nsamples
-    x = synth_stream(plan.first_sample, n_local, dev, seed=0x5EED2024 + rank)
-
-    win = windows("Hanning", nwins=nfft, verbose=False)
-    S2 = float(np.sum(win ** 2))
-    Fs = 1.0
-    scale = 1.0 / (Fs * S2)
-
-    pipe = WelchPipeline(win, plan, scale=scale, sided=E.SIDED_TWO) if world > 1 else None
+def measure(E, x, plan, win, scale, world, dist, dev, args, collective, native):
+    """settle + warm-up + EXACTLY args.steps timed steps of the hot path over this rank's shard `x` (barrier + synchronize on
+    both sides, max over ranks), then the dominant kernel's duration by HIP events in further untimed steps."""
+    if not collective:
+        pipe = None
+    elif native:           # the whole step inside libspectral: export -> ncclAllReduce (its own stream) -> apply, one call
+        pipe = NativeWelchPipeline(win, plan, scale=scale, sided=E.SIDED_TWO)
+    else:                  # torch.distributed carries the state (gloo rehearsals; SP_BENCH_NATIVE_COMM=0)
+        pipe = WelchPipeline(win, plan, scale=scale, sided=E.SIDED_TWO, force_collective=collective)
 
     def step():
         # the whole hot path: global-mean detrend (fft_analysis.py:2148) + window + overlapped FFT + |X|^2 + segment
-        # average, in ONE pass over the samples; at N>1: one all_reduce of the shard states, started asynchronously and
+        # average, in ONE pass over the samples; sharded: one all_reduce of the shard states, started asynchronously and
         # consumed one step later (pyfft_amd/dist.py: WelchPipeline) -- submit() returns the PREVIOUS step's PSD
-        if world == 1:
-            return E.welch_psd(x, win, hop, M_local, detrend=True, sided=E.SIDED_TWO, scale=scale)
+        if pipe is None:
+            return E.welch_psd(x, win, plan.hop, plan.frames, detrend=True, sided=E.SIDED_TWO, scale=scale)
         return pipe.submit(x)
 
     def drain():
         return pipe.flush() if pipe is not None else None
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
     E.profile_enable(False)          # the HIP-event hook is only switched on for the roofline measurement below
-    for _ in range(max(0, args.settle_steps)):
+    # (the clocks need ~30 ms of work: small shards get proportionally more settle steps -- a count every rank agrees on)
+    for _ in range(max(0, args.settle_steps) * max(1, (1 << 28) // max(1, plan.total_samples // plan.world))):
         step()
     drain()
     torch.cuda.synchronize()
+    pxx = None
     for _ in range(args.warmup):
         pxx = step()
     drain()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pxx = step()
     last = drain()                   # the K-th step's all-reduce and finish kernel are inside the timed region
+    t_enq = time.perf_counter() - t0
     if last is not None:
         pxx = last
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -220,32 +155,198 @@ def main():
         kd.append(E.profile_last_ms())
     drain()
     torch.cuda.synchronize()
-    k_ms = float(np.mean(kd))
+    E.profile_enable(False)
+    return {"elapsed": elapsed, "enqueue": t_enq, "kernel_ms": float(np.mean(kd)), "pxx": pxx,
+            "kernel": E.profile_last_kernel()}
+
+
+def tol_ratio(got, ref, rtol=2e-4, atol_rel=1e-6):
+    """worst |got - ref| in units of the allowance rtol |ref| + atol_rel max(ref) (<= 1 passes)"""
+    return float(np.max(np.abs(got - ref) / (rtol * np.abs(ref) + atol_rel * ref.max())))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-steps", type=int, default=60,
+                    help="untimed steps before the warm-up steps so that the GPU clocks have ramped: the first ~40 "
+                         "steps after idle run 10-25 %% slower (tools/steptrace.py).  A fixed count, not a time, so "
+                         "that every rank issues the same collectives.  0 = off")
+    ap.add_argument("--log2n", type=int, default=28,
+                    help="the stream has 2^log2n samples: split over the GPUs in the strong-scaling (headline) mode, per GPU "
+                         "in the weak-scaling mode")
+    ap.add_argument("--mode", choices=("auto", "strong", "weak", "both"), default="auto",
+                    help="N > 1: 'strong' = ONE 2^log2n-sample stream split N ways (BASELINE.json's metric; the headline "
+                         "value), 'weak' = 2^log2n samples per GPU, 'both' (= auto) = strong as the headline with the weak "
+                         "figure as an extra key.  N = 1: the two coincide")
+    ap.add_argument("--nfft", type=int, default=4096)
+    ap.add_argument("--cpu-log2n", type=int, default=28, help="CPU-baseline sample = first 2^k samples (0 = skip)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="worker processes of the all-cores CPU baseline "
+                                                             "(0 = the cores this process may run on, at most 32)")
+    ap.add_argument("--gate-log2n", type=int, default=22,
+                    help="sharded runs: the first 2^k samples of the stream go through the same sharded path and are compared "
+                         "with the CPU oracle on host-generated samples (0 = skip)")
+    args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if os.environ.get("SP_BENCH_DRYRUN", "") not in ("", "0"):
+        # launch-plumbing rehearsal for machines without a GPU (tests/test_dist_cpu.py): rendezvous over gloo, one
+        # all-reduce, the shard plans of both modes, one JSON line from rank 0 -- no kernels, not a measurement
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        ps = shard_plan(1 << args.log2n, args.nfft, args.nfft // 2, world, rank)
+        fr = torch.tensor([float(ps.frames)], dtype=torch.float64)
+        dist.all_reduce(fr)
+        if rank == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": world, "rank_sum": float(t.item()), "steps": args.steps,
+                              "strong_frames_total": ps.frames_total, "strong_frames_sum": float(fr.item())}))
+        dist.destroy_process_group()
+        return
+    dist = None
+    # rehearsal on a one-GPU box: SP_BENCH_ONE_GPU=1 puts every rank on cuda:0 and uses gloo (RCCL refuses two
+    # ranks on one device); the driver's real runs use one GPU per rank over RCCL.  SP_BENCH_FORCE_DIST=1 runs the
+    # sharded code path (WelchPipeline: export, all-reduce over an RCCL group, apply) with a world of ONE rank
+    one_gpu = os.environ.get("SP_BENCH_ONE_GPU", "") not in ("", "0")
+    force_dist = os.environ.get("SP_BENCH_FORCE_DIST", "") not in ("", "0")
+    if one_gpu:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 or force_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    collective = world > 1 or force_dist
+    # the library's own RCCL communicator (one ctypes call per step, no host work between the kernels and the collective)
+    native = collective and not one_gpu and os.environ.get("SP_BENCH_NATIVE_COMM", "1") not in ("", "0")
+    if native:
+        native_comm_init(device=local)
+
+    nfft = args.nfft
+    hop = nfft // 2
+    S = 1 << args.log2n
+    mode = args.mode
+    if mode == "auto":
+        mode = "both" if world > 1 else "strong"
+    win = windows("Hanning", nwins=nfft, verbose=False)
+    S2 = float(np.sum(win ** 2))
+    Fs = 1.0
+    scale = 1.0 / (Fs * S2)
+
+    def run(total):
+        plan = shard_plan(total, nfft, hop, world, rank)     # contiguous frame ranges + (nfft-hop)-sample halo
+        x = synth.stream_torch(plan.first_sample, plan.nsamples, dev)
+        m = measure(E, x, plan, win, scale, world, dist, dev, args, collective, native)
+        m["plan"] = plan
+        m["x"] = x
+        return m
+
+    runs = {}
+    if mode in ("strong", "both"):
+        runs["strong"] = run(S)
+    if mode in ("weak", "both") and (world > 1 or mode == "weak"):
+        if "strong" in runs:
+            runs["strong"].pop("x")                          # free the strong shard before the weak one is made
+        runs["weak"] = run(S * world)
+    head = "strong" if "strong" in runs else "weak"
+    m = runs[head]
+    plan = m["plan"]
+    total = plan.total_samples
+    elapsed, k_ms = m["elapsed"], m["kernel_ms"]
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = (total / 1e6) / (elapsed / args.steps)       # Msamples/s, whole job
-    alg_bytes = 8.0 * n_local                            # 8 B per complex64 input sample, read once
+    alg_bytes = 8.0 * plan.nsamples                      # 8 B per complex64 input sample, read once (SURVEY 8d)
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9           # GB/s
 
+    if world == 1:
+        workload = "Welch PSD, 2^%d complex64 samples, nfft=%d periodic Hann, hop=%d, global mean detrend, two-sided" \
+                   % (args.log2n, nfft, hop)
+    elif head == "strong":
+        workload = ("Welch PSD of ONE 2^%d-sample complex64 stream split over %d GPUs (2^%d/%d = %d samples + a %d-sample halo "
+                    "per GPU), nfft=%d periodic Hann, hop=%d, global mean detrend, two-sided"
+                    % (args.log2n, world, args.log2n, world, S // world, nfft - hop, nfft, hop))
+    else:
+        workload = "Welch PSD, 2^%d complex64 samples per GPU (one stream of %d samples), nfft=%d periodic Hann, hop=%d, " \
+                   "global mean detrend, two-sided" % (args.log2n, total, nfft, hop)
     result = {
         "metric": "Msamples/sec Welch-PSD 4096-pt Hann 50% overlap, complex64",
         "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": head if world > 1 else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Welch PSD, 2^%d complex64 samples per GPU, nfft=%d periodic Hann, hop=%d, "
-                               "global mean detrend, two-sided" % (args.log2n, nfft, hop),
-                   "samples_per_gpu": S, "frames_per_gpu": M_local, "settle_steps": args.settle_steps, "parallelism": "segment-sharded x%d, "
-                   "one RCCL all-reduce of the shard state (%d doubles)" % (world, 5 * nfft + 8)},
+        "config": {"workload": workload, "total_samples": total, "samples_per_gpu": plan.nsamples,
+                   "frames_per_gpu": plan.frames, "frames_total": plan.frames_total, "settle_steps": args.settle_steps,
+                   "stream": "counter-based: splitmix64(seed ^ k) -> Box-Muller + two tones + offset (synth.py), identical "
+                             "samples on every rank",
+                   "parallelism": "segment-sharded x%d, one RCCL all-reduce of the shard state (%d doubles) per step, "
+                                  "overlapped with the next step's kernels; %s" % (world, 5 * nfft + 8,
+                                  "issued by libspectral on its own stream (sp_welch_dist_submit)" if native else
+                                  "issued through torch.distributed (WelchPipeline)")
+                                  if collective else "single GPU, no collective"},
+        "host_enqueue_ms_per_step": 1e3 * m["enqueue"] / args.steps,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": pmc_traffic(args.log2n, nfft) if world == 1 else None,
-                     "kernel": "%s<%d,complex64>" % (E.profile_last_kernel(), nfft),
+                     "traffic": pmc_traffic(args.log2n, nfft) if (world == 1 and not force_dist) else None,
+                     "kernel": "%s<%d,complex64>" % (m["kernel"], nfft),
                      "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "VALU + LDS co-bound (ablation table, DESIGN.md); traffic = rocprofv3 PMC bytes of this build "
-                             "(profiles/pmc_metric_kernel_current.json) or null"},
+                     "note": "rank 0's launch over its own shard; VALU + LDS co-bound (ablation table, DESIGN.md); traffic = "
+                             "rocprofv3 PMC bytes of this build (profiles/pmc_metric_kernel_current.json) or null"},
     }
+    if "weak" in runs and head == "strong":
+        w = runs["weak"]
+        result["weak_scaling"] = {"value": (w["plan"].total_samples / 1e6) / (w["elapsed"] / args.steps),
+                                  "unit": "Msamples/s", "ms_per_step": 1e3 * w["elapsed"] / args.steps,
+                                  "samples_per_gpu": w["plan"].nsamples, "kernel_ms": w["kernel_ms"],
+                                  "note": "2^%d samples per GPU, same K steps" % args.log2n}
 
-    if rank == 0 and world == 1 and args.cpu_log2n > 0:
+    # ---- parity gates of the sharded path (outside the timed region) ---------------------------------------------------
+    if collective:
+        from pyfft_amd.dist import welch_psd_sharded
+        gates = {}
+        if args.gate_log2n > 0:
+            # (a) the first 2^k samples of the stream through the SAME sharded path (shard plan over `world` ranks, state
+            # all-reduce, apply) against the CPU oracle on host-generated samples of the same formula
+            ng = 1 << args.gate_log2n
+            pg = shard_plan(ng, nfft, hop, world, rank)
+            xg = synth.stream_torch(pg.first_sample, pg.nsamples, dev)
+            got = welch_psd_sharded(xg, win, pg, scale, sided=E.SIDED_TWO, force_collective=force_dist).cpu().numpy()
+            if rank == 0:
+                from oracle import cpu_ref as O
+                ref = O.welch_psd_stream(synth.stream_numpy(0, ng), win, nfft, hop, pg.frames_total, Fs)
+                r = tol_ratio(got, ref)
+                gates["prefix_vs_oracle"] = {"samples": ng, "vs": "oracle.welch_psd_stream on host-generated samples",
+                                             "rtol": 2e-4, "atol_rel_max": 1e-6, "worst_over_tolerance": r, "ok": bool(r <= 1.0)}
+        # (b) the timed result itself: the PSD of the whole stream from N shards against ONE GPU's PSD of the same stream
+        # (rank 0 generates all of it; the single-GPU path is oracle-gated by the N = 1 run and by tests/)
+        if rank == 0:
+            xa = synth.stream_torch(0, total, dev)
+            one = E.welch_psd(xa, win, hop, plan.frames_total, detrend=True, sided=E.SIDED_TWO, scale=scale).cpu().numpy()
+            del xa
+            r = tol_ratio(m["pxx"].cpu().numpy(), one)
+            gates["sharded_vs_single_gpu"] = {"samples": total, "rtol": 2e-4, "atol_rel_max": 1e-6,
+                                              "worst_over_tolerance": r, "ok": bool(r <= 1.0)}
+            result["parity"] = gates
+            if not all(g["ok"] for g in gates.values()):
+                result["value"] = 0.0
+                result["error"] = "parity gate failed"
+
+    if rank == 0 and world == 1 and not force_dist and args.cpu_log2n > 0:
         # CPU baseline: the oracle's streaming restatement of the same path ("port": numpy float64 pocketfft, identical
         # arithmetic to the reference's fft_win -> Pstft -> averagewins) on the first 2^k samples of the same stream,
         # (i) on ONE core -- the reference's own CPU path is single-threaded -- and (ii) on every core this process may
@@ -253,14 +354,16 @@ def main():
         # parity gate.
         from oracle import cpu_ref as O
         from oracle import cpu_parallel
+        x = m["x"]
         nc = min(S, 1 << args.cpu_log2n)
         Mc = (nc - nfft) // hop + 1
         xc = x[:nc].cpu().numpy()
+        gen = float(np.max(np.abs(xc[:1 << 16] - synth.stream_numpy(0, 1 << 16))))     # device and host generator agree
         t1 = time.perf_counter()
         ref = O.welch_psd_stream(xc, win, nfft, hop, Mc, Fs)
         tc = time.perf_counter() - t1
         got = E.welch_psd(x[:nc], win, hop, Mc, detrend=True, sided=E.SIDED_TWO, scale=scale).cpu().numpy()
-        err = float(np.max(np.abs(got - ref) / (2e-4 * np.abs(ref) + 1e-6 * ref.max())))
+        err = tol_ratio(got, ref)
         one = {"value": (nc / 1e6) / tc, "unit": "Msamples/s", "cores": 1, "seconds": tc}
         cores = cpu_parallel.usable_cores(args.cpu_cores)
         result["cpu_baseline"] = dict(one, kind="port",
@@ -280,14 +383,18 @@ def main():
             except Exception as exc:                       # a box that refuses worker processes keeps the one-core line
                 result["cpu_baseline"]["all_cores_error"] = repr(exc)
         result["parity"] = {"vs": "oracle.welch_psd_stream on the CPU sample", "rtol": 2e-4, "atol_rel_max": 1e-6,
-                            "worst_over_tolerance": err, "ok": bool(err <= 1.0)}
-        if err > 1.0:
+                            "worst_over_tolerance": err, "ok": bool(err <= 1.0),
+                            "device_vs_host_generator_max_abs": gen}
+        if err > 1.0 or gen > 1e-5:
             result["value"] = 0.0
             result["error"] = "parity gate failed"
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if native:
+        torch.cuda.synchronize()
+        E.comm_destroy()
+    if dist is not None:
         dist.destroy_process_group()
 
 

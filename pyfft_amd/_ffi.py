@@ -39,6 +39,13 @@ SIGNATURES = {
     "sp_welch_finish": (_i, [_vp, _i64, _i, _d, _vp, _i]),
     "sp_welch_export": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i64, _vp, _i]),
     "sp_welch_apply": (_i, [_vp, _vp, _i, _i64, _i, _d, _vp, _i]),
+    "sp_comm_unique_id": (_i, [_vp]),
+    "sp_comm_init": (_i, [_vp, _i, _i]),
+    "sp_comm_info": (_i, [C.POINTER(_i)]),
+    "sp_comm_destroy": (_i, []),
+    "sp_welch_dist_submit": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i64, _i64, _i, _d, _vp, C.POINTER(_i), _i]),
+    "sp_welch_dist_flush": (_i, [_vp, C.POINTER(_i), _i]),
+    "sp_welch_psd_dist": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i64, _i64, _i, _d, _vp, _i]),
     "sp_welch_csd": (_i, [_vp, _vp, _i, _i64, _i, _i64, _vp, _i, _i, _i64, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _i]),
     "sp_csd_matrix": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i, _i64, _i, _d, _vp, _i]),
     "sp_csd_matrix_means": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i, _i64, _vp, _d, _vp, _i]),

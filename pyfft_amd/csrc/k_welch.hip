@@ -210,6 +210,23 @@ int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, 
     return 0;
 }
 
+int launch_op_fused(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, const float *partial,
+                    const cf *spartial, int64_t G, int n, int hop, int64_t nframes, int64_t nmean, OnePass st, unsigned *ticket,
+                    CogLobe lb, const double *mean_in, int sided, double scale, double *out, bool export_state) {
+    if (n % hop != 0 || lb.K < 0 || lb.K > 3 || n < 2 * lb.K + 2) return -1;
+    const dim3 grid((n + 31) / 32 + (2 * hop + 31) / 32), block(1024);
+#define FUSED_(CP, EX)                                                                                 \
+    hipLaunchKernelGGL((k_op_fused<CP, EX>), grid, block, 0, c.stream, partial, n, st.A, reinterpret_cast<const float *>(spartial), \
+                       hop, st.Sl, G, ticket, x, trend, win, lb, mean_in, nframes, nmean, sided, scale, out, st.sym)
+    if (cplx) {
+        if (export_state) FUSED_(true, true); else FUSED_(true, false);
+    } else {
+        if (export_state) FUSED_(false, true); else FUSED_(false, false);
+    }
+#undef FUSED_
+    return 0;
+}
+
 int launch_op_apply(LaunchCtx c, const double *state, const cf *Wf, int n, int sided, double scale, double *out) {
     hipLaunchKernelGGL(k_op_apply, dim3((n + 255) / 256), dim3(256), 0, c.stream, state, Wf, n, sided, scale, out);
     return 0;

@@ -1991,6 +1991,231 @@ static __global__ void k_cog_finish_op(const cf *__restrict__ acc, int wpf, int6
     out[g] = den > 0.0 ? df * num / den : 0.0;
 }
 
+// ---- the one-pass Welch epilogue in ONE launch, for windows whose spectrum is confined to the bins -3 .. 3 -------------
+// k_op_colsums + k_op_finish are two launches, the second one a single workgroup running a chain of memory round trips and a
+// transform: 7 + 19 us of kernels and two boundaries per step, a third of a 2^25-sample shard's step (strong scaling at 8
+// GPUs).  The transform B = FFT(w c) = sum_g X_g is only needed where W = FFT(window) is non-zero, P[k] = A[k] -
+// 2 Re(conj(d W[k]) B[k]) + M |d W[k]|^2: for the periodic cosine-sum windows (Hann, Hamming, Blackman, Nuttall, the flat-top
+// family: everything the reference's windows() builds but Kaiser / Chebyshev) these are the bins ks = -K .. K, K <= 3 (CogLobe,
+// float64 from the host, checked by Parseval) -- 2K + 1 direct sums over n instead of a transform.  So: the column-sum grid
+// (same blocks, same order of additions as k_op_colsums: bit-identical A and Sl), a release fence + ticket per block, and the
+// block that arrives last (no spinning: nothing waits for another block) finishes: exact mean from the block sums, c[n], the
+// lobe bins of B in float64, and the spectrum / the additive shard state.  `ticket` is zero on entry and is left zero.
+// EXPORT: out = the state of k_op_finish<EXPORT> (A | B | conj(mu0) B | scalars) with B zero outside the lobe bins, which is
+// all k_op_apply multiplies by a non-zero W.
+__device__ __forceinline__ double wave_sum64d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <bool CPLX, bool EXPORT>
+static __global__ __launch_bounds__(1024) void k_op_fused(const float *__restrict__ m0, int N, double *__restrict__ Acol,
+                                                           const float *__restrict__ m1, int H, double *__restrict__ Sl,
+                                                           int64_t G, unsigned *__restrict__ ticket,
+                                                           const void *__restrict__ x, const float *__restrict__ trend,
+                                                           const float *__restrict__ win, CogLobe lb,
+                                                           const double *__restrict__ mean_in, int64_t M, int64_t nmean,
+                                                           int sided, double scale, double *__restrict__ out, int sym) {
+    __shared__ double sh[32][32];
+    __shared__ int last_flag;
+    {   // ---- phase 1: k_op_colsums' body (columns of m0 [G][N] -> Acol, of m1 [G][2H] -> Sl)
+        const int c0 = N, c1 = 2 * H;
+        const int nb0 = (c0 + 31) / 32;
+        const bool second = (int)blockIdx.x >= nb0;
+        const float *__restrict__ m = second ? m1 : m0;
+        const int cols = second ? c1 : c0;
+        double *__restrict__ o = second ? Sl : Acol;
+        const int lane = threadIdx.x % 32, sl = threadIdx.x / 32;
+        const int k = ((int)blockIdx.x - (second ? nb0 : 0)) * 32 + lane;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        if (k < cols) {
+            int64_t g = sl;
+            for (; g + 96 < G; g += 128) {
+                const float a0 = m[g * cols + k], a1 = m[(g + 32) * cols + k], a2 = m[(g + 64) * cols + k], a3 = m[(g + 96) * cols + k];
+                s0 += (double)a0;
+                s1 += (double)a1;
+                s2 += (double)a2;
+                s3 += (double)a3;
+            }
+            for (; g < G; g += 32) s0 += (double)m[g * cols + k];
+        }
+        sh[sl][lane] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (sl == 0 && k < cols) {
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) t += sh[q][lane];
+            o[k] = t;
+        }
+    }
+    // ---- hand-off: the stores above all come from wave 0; its lane 0 drains them, releases at agent scope and takes a ticket
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == gridDim.x - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    // ---- phase 2 (the last block to arrive; every Acol / Sl value is visible now)
+    double *red = &sh[0][0];                   // 16 waves x up to 16 values
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    const cf mu = mk(trend[0], trend[1]);
+    const int r = N / H;
+    const int64_t head = (int64_t)(r - 1) * H, cov = (M + r - 1) * (int64_t)H;
+    double tot_r = 0.0, tot_i = 0.0, dr, di;
+    if (!EXPORT && mean_in) {
+        dr = mean_in[0] - (double)trend[0];
+        di = mean_in[1] - (double)trend[1];
+    } else {
+        // sum_{i < nmean} (x[i] - mu0) = all block sums + the head blocks -/+ the ragged end (as k_op_finish)
+        double a = 0.0, b = 0.0;
+        for (int j = threadIdx.x; j < H; j += 1024) {
+            a += Sl[2 * j];
+            b += Sl[2 * j + 1];
+        }
+        for (int64_t i = threadIdx.x; i < head; i += 1024) {
+            const cf v = load_sample(x, i, CPLX);
+            a += (double)(v.x - mu.x);
+            b += (double)(v.y - mu.y);
+        }
+        const int64_t lo = nmean > cov ? cov : nmean, hi = nmean > cov ? nmean : cov;
+        const double sgn = nmean > cov ? 1.0 : -1.0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) {
+            const cf v = load_sample(x, i, CPLX) - mu;
+            a += sgn * v.x;
+            b += sgn * v.y;
+        }
+        a = wave_sum64d(a);
+        b = wave_sum64d(b);
+        __syncthreads();
+        if (ln == 0) {
+            red[2 * wv] = a;
+            red[2 * wv + 1] = b;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            tot_r += red[2 * w];
+            tot_i += red[2 * w + 1];
+        }
+        dr = tot_r / (double)nmean;
+        di = tot_i / (double)nmean;
+    }
+    // B[ks] = sum_n w[n] c[n] e^{-2 pi i ks n / N}, ks = -3 .. 3, c[n] = sum_g x_g[n] rebuilt from the block sums and the edge blocks
+    double br[7], bi[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) br[q] = bi[q] = 0.0;
+    for (int nidx = threadIdx.x; nidx < N; nidx += 1024) {
+        const int q = nidx / H, j = nidx % H;
+        double a = Sl[2 * j], b = Sl[2 * j + 1];
+        for (int bb = q; bb <= r - 2; ++bb) {
+            const cf v = load_sample(x, (int64_t)bb * H + j, CPLX) - mu;
+            a += v.x;
+            b += v.y;
+        }
+        for (int64_t bb = M + q; bb <= M + r - 2; ++bb) {
+            const cf v = load_sample(x, bb * H + j, CPLX) - mu;
+            a -= v.x;
+            b -= v.y;
+        }
+        const double wn = (double)win[nidx];
+        a *= wn;
+        b *= wn;
+        double s1, c1;
+        sincospi(-2.0 * (double)nidx / (double)N, &s1, &c1);          // e^{-i theta}, theta = 2 pi n / N
+        br[3] += a;
+        bi[3] += b;
+        double pr = 1.0, pi_ = 0.0;
+#pragma unroll
+        for (int ks = 1; ks <= 3; ++ks) {
+            const double tr_ = pr * c1 - pi_ * s1, ti_ = pr * s1 + pi_ * c1;      // e^{-i ks theta}
+            pr = tr_;
+            pi_ = ti_;
+            br[3 + ks] += a * pr - b * pi_;
+            bi[3 + ks] += a * pi_ + b * pr;
+            br[3 - ks] += a * pr + b * pi_;                                     // conj phase for -ks
+            bi[3 - ks] += b * pr - a * pi_;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        br[q] = wave_sum64d(br[q]);
+        bi[q] = wave_sum64d(bi[q]);
+    }
+    __syncthreads();
+    if (ln == 0) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            red[16 * wv + 2 * q] = br[q];
+            red[16 * wv + 2 * q + 1] = bi[q];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            a += red[16 * w + 2 * q];
+            b += red[16 * w + 2 * q + 1];
+        }
+        br[q] = a;
+        bi[q] = b;
+    }
+    const double mr = (double)mu.x, mi = (double)mu.y;
+    for (int k = threadIdx.x; k < N; k += 1024) {
+        const double a = sym ? 0.5 * (Acol[k] + Acol[(N - k) & (N - 1)]) : Acol[k];
+        const int ks = k <= lb.K ? k : (k >= N - lb.K ? k - N : 99);
+        const bool in = ks != 99;
+        double Br = 0.0, Bi = 0.0, wr = 0.0, wi = 0.0;
+        if (in) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q)
+                if (q == ks + 3) {
+                    Br = br[q];
+                    Bi = bi[q];
+                    wr = lb.wr[q];
+                    wi = lb.wi[q];
+                }
+        }
+        if constexpr (EXPORT) {
+            out[k] = a;
+            out[N + 2 * k] = Br;
+            out[N + 2 * k + 1] = Bi;
+            out[3 * N + 2 * k] = mr * Br + mi * Bi;          // conj(mu0) B
+            out[3 * N + 2 * k + 1] = mr * Bi - mi * Br;
+        } else {
+            const int slot = bin_slot(k, N, sided);
+            if (slot >= 0) {
+                const double er = dr * wr - di * wi, ei = dr * wi + di * wr;       // d W[k]
+                const double p = a - 2.0 * (er * Br + ei * Bi) + (double)M * (er * er + ei * ei);
+                out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        if constexpr (EXPORT) {
+            double *sc = out + 5 * (int64_t)N;
+            sc[0] = (double)M * mr;
+            sc[1] = (double)M * mi;
+            sc[2] = (double)M * (mr * mr + mi * mi);
+            sc[3] = tot_r + (double)nmean * mr;
+            sc[4] = tot_i + (double)nmean * mi;
+            sc[5] = (double)M;
+            sc[6] = (double)nmean;
+            sc[7] = 0.0;
+        }
+        *ticket = 0u;                       // ready for the next launch (ordered by the kernel boundary)
+    }
+}
+
 // Real input STFT, two frames per transform: z = f_g + i f_{g+1};  X_g = (Z[k] + conj Z[n-k]) / 2,
 // X_{g+1} = (Z[k] - conj Z[n-k]) / (2i).  The mirror comes from one more LDS exchange (linear image, reversed read).
 // Power-of-two n only (mirror index by masking); the other lengths use k_stft.

@@ -4,6 +4,8 @@
 #include "table_cache.h"
 
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>          // types and enums only: the functions are resolved with dlsym (no link-time dependency)
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -17,7 +19,7 @@
 
 using namespace sp;
 
-#define SP_VERSION 104
+#define SP_VERSION 105
 #define SP_MAX_WG_FFT 8192
 #define SP_MAX_BIG_LOG2 26          /* longest multi-pass power-of-two transform: 2^26 points (512 MiB per buffer) */
 
@@ -78,7 +80,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     std::map<int64_t, cf *> twiddles;   // L -> exp(-2 pi i m/L)
     std::map<int64_t, BlueTab> blue;    // n -> Bluestein tables
-    Scratch in0, in1, out0, work, small, trends, onepass;
+    Scratch in0, in1, out0, work, small, trends, onepass, ticket;
     Scratch pend_trend;                       // trend record a pending sp_welch_accum keeps until sp_welch_finish
     Scratch bigA, bigB, bigT, blueA, blueB, longrec;   // long (multi-kernel) paths
     Scratch cmS, cmT, cmG, cmH, cmO;               // CSD matrix: spectra, bin-major spectra, float64 accumulator, packed-spectra sums, one-pass means state
@@ -625,10 +627,77 @@ static bool welch_pipe_wanted(const Xf &xf, int hop, int64_t nframes) {
     return welch_pipe_eligible(xf, hop) && (mode >= 2 || (mode == 1 && nframes >= 32 * (int64_t)g.ncu));
 }
 
+// FFT(window) on the host in float64, to find out whether it is confined to the bins ks = -K .. K, K <= 3 (periodic cosine-sum
+// windows: Hann, Hamming, Blackman, Nuttall ...): everything outside below 1e-9 of the peak.  Cached under the window's content.
+static bool cog_window_lobe(const float *win, int n, CogLobe *lb) {
+    struct Entry {
+        uint64_t key;
+        int n;
+        bool ok;
+        CogLobe lb;
+    };
+    static std::vector<Entry> cache;
+    uint64_t h = 1469598103934665603ull;
+    for (int i = 0; i < n; ++i) {
+        uint32_t u;
+        memcpy(&u, win + i, 4);
+        h = (h ^ u) * 1099511628211ull;
+    }
+    for (const Entry &e : cache)
+        if (e.key == h && e.n == n) {
+            *lb = e.lb;
+            return e.ok;
+        }
+    Entry e{h, n, false, CogLobe{}};
+    // the lobe bins exactly, and the energy outside them by Parseval: sum |W|^2 = n sum w^2
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) tot += (double)win[i] * (double)win[i];
+    tot *= (double)n;
+    double in = 0.0, peak = 0.0;
+    CogLobe l{};
+    l.K = 3;
+    for (int ks = -3; ks <= 3; ++ks) {
+        double re = 0.0, im = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double a = -2.0 * M_PI * (double)(((int64_t)ks * i) % n) / (double)n;
+            re += (double)win[i] * std::cos(a);
+            im += (double)win[i] * std::sin(a);
+        }
+        l.wr[ks + 3] = re;
+        l.wi[ks + 3] = im;
+        in += re * re + im * im;
+        if (re * re + im * im > peak) peak = re * re + im * im;
+    }
+    e.ok = peak > 0.0 && std::fabs(tot - in) <= 1e-9 * tot;      // (float32 window values: the tables' own rounding leaks ~1e-14)
+    e.lb = l;
+    if (cache.size() < 64) cache.push_back(e);
+    *lb = l;
+    return e.ok;
+}
+
+
+// request for the epilogue in the same call (k_op_fused: column sums + finish / export in ONE launch; taken when the window's
+// spectrum is confined to the bins -3 .. 3 -- every cosine-sum window -- unless SP_OP_UNFUSED=1): done = true on return when
+// `out` has been produced, otherwise the caller runs k_op_finish as before
+struct FusedOut {
+    bool export_state;
+    int sided;
+    double scale;          // already divided by the frame count
+    double *out;
+    bool done;
+};
+unsigned *get_ticket() {
+    if (!g.ticket.p) {
+        if (g.ticket.ensure(256)) return nullptr;
+        if (hipMemset(g.ticket.p, 0, 256) != hipSuccess) return nullptr;
+    }
+    return (unsigned *)g.ticket.p;
+}
+
 // want_sum: also produce the shard's plain sample sum (split ABI, one more tiny launch); without it the finish kernel
 // derives the shard mean itself
 int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-                       int64_t nmean, bool want_sum) {
+                       int64_t nmean, bool want_sum, FusedOut *fo = nullptr) {
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
     if (!welch_carry_eligible(xf, hop, false))
@@ -686,6 +755,16 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
                                spartial, &g.last_kernel));
     }
     if (!want_sum) st.dlt = nullptr;
+    CogLobe lobe{};
+    if (fo && !want_sum && !env_flag("SP_OP_UNFUSED") && cog_window_lobe(win, nfft, &lobe)) {
+        unsigned *ticket = get_ticket();
+        if (!ticket) return fail("ticket allocation failed");
+        LAUNCHCHK(launch_op_fused(lc(), xd, cplx, tb.f, (const float *)win_d, partial, spartial, rp.groups, nfft, hop, nframes, nmean,
+                                  st, ticket, lobe, nullptr, fo->sided, fo->scale, fo->out, fo->export_state));
+        fo->done = true;
+        g_pend.valid = false;
+        return 0;
+    }
     LAUNCHCHK(launch_op_reduce(lc(), xd, cplx, tb.f, partial, spartial, rp.groups, xf, hop, nframes, nmean, st,
                                want_sum ? sum_d : nullptr));
     g_pend.valid = true;
@@ -713,6 +792,86 @@ int welch_finish_locked(const double *mean_d /*device or null*/, int64_t frames_
     LAUNCHCHK(launch_op_finish(lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, mean_d, g_pend.nmean,
                                g_pend.xf, g_pend.hop, g_pend.nframes, g_pend.cw, g_pend.Wf, sided,
                                scale / (double)frames_total, out_d));
+    return 0;
+}
+
+// ---- RCCL inside the library: one process per GPU, the library owns a communicator and a stream for the collective ---------
+// The functions come from the RCCL that is already in the process when there is one (torch ships its own copy under the
+// same soname, so dlopen returns that instance), else from /opt/rocm/lib.
+struct Rccl {
+    void *dl = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+} rccl;
+
+int rccl_load() {
+    if (rccl.dl) return 0;
+    const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void *h = nullptr;
+    for (const char *nm : names)
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail("RCCL not found (librccl.so.1): %s", dlerror());
+    *(void **)&rccl.GetUniqueId = dlsym(h, "ncclGetUniqueId");
+    *(void **)&rccl.CommInitRank = dlsym(h, "ncclCommInitRank");
+    *(void **)&rccl.CommDestroy = dlsym(h, "ncclCommDestroy");
+    *(void **)&rccl.AllReduce = dlsym(h, "ncclAllReduce");
+    *(void **)&rccl.GetErrorString = dlsym(h, "ncclGetErrorString");
+    if (!rccl.GetUniqueId || !rccl.CommInitRank || !rccl.CommDestroy || !rccl.AllReduce || !rccl.GetErrorString)
+        return fail("librccl lacks an expected symbol");
+    rccl.dl = h;
+    return 0;
+}
+#define NCCLCHK(expr)                                                                                 \
+    do {                                                                                              \
+        ncclResult_t r_ = (expr);                                                                     \
+        if (r_ != ncclSuccess) return fail("%s failed: %s (%s:%d)", #expr, rccl.GetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+
+// one step of the pipelined sharded PSD waiting for its all-reduce
+struct DistSlot {
+    bool valid = false;
+    std::vector<float> win;
+    int64_t frames_total = 0;
+    int sided = 0;
+    double scale = 0;
+};
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int world = 0, rank = -1;
+    hipStream_t cs = nullptr;                       // the collective's own stream
+    hipEvent_t ev_exp[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
+    Scratch st[2];                                  // the two state buffers in flight
+    DistSlot slot[2];
+    int cur = 0;
+} gcomm;
+
+// finish slot s: wait (on the launch stream) for its all-reduce, apply the global mean -> out_d (device)
+int dist_apply_locked(int s, double *out_d) {
+    DistSlot &sl = gcomm.slot[s];
+    const int nfft = (int)sl.win.size();
+    Xf xf;
+    if (get_xf(nfft, &xf)) return -1;
+    void *Wf_d;
+    if (get_window_spectrum(sl.win.data(), nfft, xf, &Wf_d)) return -1;
+    HIPCHK(hipStreamWaitEvent(g.stream, gcomm.ev_red[s], 0));
+    LAUNCHCHK(launch_op_apply(lc(), (const double *)gcomm.st[s].p, (const cf *)Wf_d, nfft, sl.sided, sl.scale / (double)sl.frames_total,
+                              out_d));
+    sl.valid = false;
+    return 0;
+}
+
+// this shard's additive state (sp_welch_export) into st_d (device, 5 nfft + 8 doubles)
+int welch_export_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+                        int64_t nmean, double *st_d) {
+    FusedOut fo{true, SP_SIDED_RAW, 1.0, st_d, false};
+    if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, false, &fo)) return -1;
+    g_pend.valid = false;
+    if (fo.done) return 0;
+    LAUNCHCHK(launch_op_finish(lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, nullptr, g_pend.nmean,
+                               g_pend.xf, g_pend.hop, g_pend.nframes, g_pend.cw, g_pend.Wf, SP_SIDED_RAW, 1.0, st_d, true));
     return 0;
 }
 
@@ -751,6 +910,7 @@ int sp_init(int device_id) {
 }
 
 void sp_shutdown(void) {
+    (void)sp_comm_destroy();
     std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return;
     (void)hipDeviceSynchronize();
@@ -768,6 +928,7 @@ void sp_shutdown(void) {
     g.small.release();
     g.trends.release();
     g.onepass.release();
+    g.ticket.release();
     g.pend_trend.release();
     g.cmS.release();
     g.cmT.release();
@@ -951,8 +1112,9 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
                (cplx || (2 * hop == nfft && nframes >= 2 && !env_flag("SP_NO_REALPAIR") &&
                          welch_pipe_wanted(xf, hop, (nframes + 1) / 2)))) {
         // global-mean detrend in ONE pass over the signal (estimate + exact correction in the epilogue)
-        if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nsig, false)) return -1;
-        if (welch_finish_locked(nullptr, nframes, sided, scale, out_d)) return -1;
+        FusedOut fo{false, sided, scale / (double)nframes, out_d, false};
+        if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nsig, false, &fo)) return -1;
+        if (!fo.done && welch_finish_locked(nullptr, nframes, sided, scale, out_d)) return -1;
     } else {
         void *win_d;
         if (get_table(1, win, sizeof(float) * (size_t)nfft, &win_d, nullptr)) return -1;
@@ -1057,16 +1219,13 @@ int sp_welch_export(const void *x, int x_dtype, int64_t nsig, const float *win, 
         HIPCHK(hipMemcpyAsync(g.in0.p, x, esz * (size_t)nsig, hipMemcpyHostToDevice, g.stream));
         xd = g.in0.p;
     }
-    if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, false)) return -1;
-    g_pend.valid = false;
     const size_t nst = 5 * (size_t)nfft + 8;
     double *st_d = state;
     if (!mem) {
         if (g.out0.ensure(sizeof(double) * nst)) return -1;
         st_d = (double *)g.out0.p;
     }
-    LAUNCHCHK(launch_op_finish(lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, nullptr, g_pend.nmean,
-                               g_pend.xf, g_pend.hop, g_pend.nframes, g_pend.cw, g_pend.Wf, SP_SIDED_RAW, 1.0, st_d, true));
+    if (welch_export_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, st_d)) return -1;
     if (!mem) {
         HIPCHK(hipMemcpyAsync(state, st_d, sizeof(double) * nst, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -1102,6 +1261,157 @@ int sp_welch_apply(const double *state, const float *win, int nfft, int64_t fram
         HIPCHK(hipStreamSynchronize(g.stream));
     }
     return 0;
+}
+
+/* ---- multi-GPU inside the library: one process per GPU, RCCL over xGMI --------------------------------------------------- */
+int sp_comm_unique_id(void *id_out) {
+    if (!id_out) return fail("sp_comm_unique_id: null pointer");
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (rccl_load()) return -1;
+    static_assert(sizeof(ncclUniqueId) == SP_COMM_ID_BYTES, "ncclUniqueId size");
+    ncclUniqueId id;
+    NCCLCHK(rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+int sp_comm_init(const void *id_in, int world, int rank) {
+    if (ensure_init()) return -1;
+    if (!id_in || world < 1 || rank < 0 || rank >= world) return fail("sp_comm_init: bad id/world/rank");
+    ApiLock lk;
+    if (gcomm.comm) return fail("sp_comm_init: a communicator exists already (sp_comm_destroy first)");
+    if (rccl_load()) return -1;
+    HIPCHK(hipSetDevice(g.device));
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    NCCLCHK(rccl.CommInitRank(&gcomm.comm, world, id, rank));
+    gcomm.world = world;
+    gcomm.rank = rank;
+    HIPCHK(hipStreamCreateWithFlags(&gcomm.cs, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&gcomm.ev_exp[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&gcomm.ev_red[i], hipEventDisableTiming));
+        gcomm.slot[i].valid = false;
+    }
+    gcomm.cur = 0;
+    return 0;
+}
+
+int sp_comm_info(int out[2]) {
+    out[0] = gcomm.comm ? gcomm.world : 0;
+    out[1] = gcomm.comm ? gcomm.rank : -1;
+    return 0;
+}
+
+int sp_comm_destroy(void) {
+    std::lock_guard<std::mutex> lk(g.mu);
+    if (!gcomm.comm) return 0;
+    (void)hipStreamSynchronize(gcomm.cs);
+    (void)hipStreamSynchronize(g.stream);
+    (void)rccl.CommDestroy(gcomm.comm);
+    gcomm.comm = nullptr;
+    gcomm.world = 0;
+    gcomm.rank = -1;
+    for (int i = 0; i < 2; ++i) {
+        (void)hipEventDestroy(gcomm.ev_exp[i]);
+        (void)hipEventDestroy(gcomm.ev_red[i]);
+        gcomm.ev_exp[i] = gcomm.ev_red[i] = nullptr;
+        gcomm.st[i].release();
+        gcomm.slot[i].valid = false;
+    }
+    (void)hipStreamDestroy(gcomm.cs);
+    gcomm.cs = nullptr;
+    return 0;
+}
+
+int sp_welch_dist_submit(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+                         int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_prev, int *have_prev,
+                         int mem) {
+    if (ensure_init()) return -1;
+    if (check_frames("sp_welch_dist_submit", nsig, nfft, hop, nframes)) return -1;
+    if (sided < 1 || sided > 3) return fail("sp_welch_dist_submit: bad sided");
+    if (frames_total < nframes) return fail("sp_welch_dist_submit: frames_total is the frame count of the WHOLE stream");
+    if (have_prev) *have_prev = 0;
+    ApiLock lk;
+    if (!gcomm.comm) return fail("sp_welch_dist_submit: no communicator (sp_comm_init)");
+    const bool cplx = x_dtype == SP_DTYPE_C64;
+    const size_t esz = cplx ? 8 : 4;
+    const void *xd = x;
+    if (!mem) {
+        if (g.in0.ensure(esz * (size_t)nsig)) return -1;
+        HIPCHK(hipMemcpyAsync(g.in0.p, x, esz * (size_t)nsig, hipMemcpyHostToDevice, g.stream));
+        xd = g.in0.p;
+    }
+    const int s = gcomm.cur, o = 1 - s;
+    if (gcomm.slot[s].valid) return fail("sp_welch_dist_submit: internal slot still busy");
+    const size_t nst = 5 * (size_t)nfft + 8;
+    if (gcomm.st[s].ensure(sizeof(double) * nst)) return -1;
+    double *st_d = (double *)gcomm.st[s].p;
+    // this step: the shard's additive state on the launch stream, its all-reduce on the collective's stream behind an event
+    if (welch_export_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, st_d)) return -1;
+    HIPCHK(hipEventRecord(gcomm.ev_exp[s], g.stream));
+    HIPCHK(hipStreamWaitEvent(gcomm.cs, gcomm.ev_exp[s], 0));
+    NCCLCHK(rccl.AllReduce(st_d, st_d, nst, ncclDouble, ncclSum, gcomm.comm, gcomm.cs));
+    HIPCHK(hipEventRecord(gcomm.ev_red[s], gcomm.cs));
+    gcomm.slot[s].valid = true;
+    gcomm.slot[s].win.assign(win, win + nfft);
+    gcomm.slot[s].frames_total = frames_total;
+    gcomm.slot[s].sided = sided;
+    gcomm.slot[s].scale = scale;
+    gcomm.cur = o;
+    // the previous step: its all-reduce has had this step's kernels to complete
+    if (gcomm.slot[o].valid) {
+        if (!pxx_prev) return fail("sp_welch_dist_submit: a previous step is pending and pxx_prev is null");
+        const int nb = nbins_host((int)gcomm.slot[o].win.size(), gcomm.slot[o].sided);
+        double *out_d = pxx_prev;
+        if (!mem) {
+            if (g.out0.ensure(sizeof(double) * (size_t)nb)) return -1;
+            out_d = (double *)g.out0.p;
+        }
+        if (dist_apply_locked(o, out_d)) return -1;
+        if (!mem) {
+            HIPCHK(hipMemcpyAsync(pxx_prev, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream));
+        }
+        if (have_prev) *have_prev = 1;
+    }
+    return 0;
+}
+
+int sp_welch_dist_flush(double *pxx_out, int *have, int mem) {
+    if (ensure_init()) return -1;
+    if (have) *have = 0;
+    ApiLock lk;
+    if (!gcomm.comm) return fail("sp_welch_dist_flush: no communicator (sp_comm_init)");
+    const int o = 1 - gcomm.cur;                      // the slot submitted last
+    if (!gcomm.slot[o].valid) return 0;
+    if (!pxx_out) return fail("sp_welch_dist_flush: a step is pending and pxx_out is null");
+    const int nb = nbins_host((int)gcomm.slot[o].win.size(), gcomm.slot[o].sided);
+    double *out_d = pxx_out;
+    if (!mem) {
+        if (g.out0.ensure(sizeof(double) * (size_t)nb)) return -1;
+        out_d = (double *)g.out0.p;
+    }
+    if (dist_apply_locked(o, out_d)) return -1;
+    if (!mem) {
+        HIPCHK(hipMemcpyAsync(pxx_out, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
+    }
+    if (have) *have = 1;
+    return 0;
+}
+
+int sp_welch_psd_dist(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
+                      int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_out, int mem) {
+    {
+        std::lock_guard<std::mutex> lk(g.mu);
+        if (gcomm.comm && (gcomm.slot[0].valid || gcomm.slot[1].valid))
+            return fail("sp_welch_psd_dist: a pipelined step is pending (sp_welch_dist_flush first)");
+    }
+    int have = 0;
+    if (sp_welch_dist_submit(x, x_dtype, nsig, win, nfft, hop, nframes, nmean, frames_total, sided, scale, nullptr, &have, mem))
+        return -1;
+    return sp_welch_dist_flush(pxx_out, &have, mem);
 }
 
 int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch, int64_t y_ld, const float *win,
@@ -1595,54 +1905,6 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
         HIPCHK(hipStreamSynchronize(g.stream));
     }
     return 0;
-}
-
-// FFT(window) on the host in float64, to find out whether it is confined to the bins ks = -K .. K, K <= 3 (periodic cosine-sum
-// windows: Hann, Hamming, Blackman, Nuttall ...): everything outside below 1e-9 of the peak.  Cached under the window's content.
-static bool cog_window_lobe(const float *win, int n, CogLobe *lb) {
-    struct Entry {
-        uint64_t key;
-        int n;
-        bool ok;
-        CogLobe lb;
-    };
-    static std::vector<Entry> cache;
-    uint64_t h = 1469598103934665603ull;
-    for (int i = 0; i < n; ++i) {
-        uint32_t u;
-        memcpy(&u, win + i, 4);
-        h = (h ^ u) * 1099511628211ull;
-    }
-    for (const Entry &e : cache)
-        if (e.key == h && e.n == n) {
-            *lb = e.lb;
-            return e.ok;
-        }
-    Entry e{h, n, false, CogLobe{}};
-    // the lobe bins exactly, and the energy outside them by Parseval: sum |W|^2 = n sum w^2
-    double tot = 0.0;
-    for (int i = 0; i < n; ++i) tot += (double)win[i] * (double)win[i];
-    tot *= (double)n;
-    double in = 0.0, peak = 0.0;
-    CogLobe l{};
-    l.K = 3;
-    for (int ks = -3; ks <= 3; ++ks) {
-        double re = 0.0, im = 0.0;
-        for (int i = 0; i < n; ++i) {
-            const double a = -2.0 * M_PI * (double)(((int64_t)ks * i) % n) / (double)n;
-            re += (double)win[i] * std::cos(a);
-            im += (double)win[i] * std::sin(a);
-        }
-        l.wr[ks + 3] = re;
-        l.wi[ks + 3] = im;
-        in += re * re + im * im;
-        if (re * re + im * im > peak) peak = re * re + im * im;
-    }
-    e.ok = peak > 0.0 && std::fabs(tot - in) <= 1e-9 * tot;      // (float32 window values: the tables' own rounding leaks ~1e-14)
-    e.lb = l;
-    if (cache.size() < 64) cache.push_back(e);
-    *lb = l;
-    return e.ok;
 }
 
 int sp_stft_cog(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,

@@ -48,19 +48,20 @@ def _device_backend():
     return export, apply
 
 
-def welch_psd_sharded(x_local, win, plan, scale=1.0, sided=2, group=None, backend=None):
+def welch_psd_sharded(x_local, win, plan, scale=1.0, sided=2, group=None, backend=None, force_collective=False):
     """Welch PSD of the whole stream from this rank's shard (global-mean detrend) with ONE collective: every rank
     exports its additive state (sum|X|^2, sum X, conj(mu0) sum X per bin against its own mean estimate mu0, plus a few
     scalars: 5 nfft + 8 doubles, 160 KiB at nfft = 4096 -- latency-bound on any topology), the states are summed with
     one all_reduce, and every rank applies the global mean to the sum.  `backend` = (export, apply) callables; default:
-    the HIP kernels (sp_welch_export / sp_welch_apply).  With world == 1 no collective is issued."""
+    the HIP kernels (sp_welch_export / sp_welch_apply).  With world == 1 no collective is issued unless force_collective
+    (a process group of one rank: the RCCL call path on a one-GPU box)."""
     import torch
     import torch.distributed as dist
     export, apply = backend if backend is not None else _device_backend()
     s = export(x_local, win, plan.hop, plan.frames, plan.own_samples)
     is_t = isinstance(s, torch.Tensor)
     st = s if is_t else torch.from_numpy(np.ascontiguousarray(s, dtype=np.float64))
-    if plan.world > 1:
+    if plan.world > 1 or force_collective:
         dist.all_reduce(st, group=group)
     return apply(st if is_t else st.numpy(), win, plan.frames_total, sided, scale)
 
@@ -75,8 +76,9 @@ class WelchPipeline(object):
     step to complete; it returns the previous step's PSD (None on the first call).  `flush()` finishes the last one.
     K submits + one flush do exactly the work of K welch_psd_sharded calls."""
 
-    def __init__(self, win, plan, scale=1.0, sided=2, group=None, backend=None):
+    def __init__(self, win, plan, scale=1.0, sided=2, group=None, backend=None, force_collective=False):
         self.win, self.plan, self.scale, self.sided, self.group = win, plan, scale, sided, group
+        self.collective = plan.world > 1 or force_collective       # (forced: a process group of ONE rank still issues it)
         self.export, self.apply = backend if backend is not None else _device_backend()
         self._pending = None
 
@@ -93,13 +95,51 @@ class WelchPipeline(object):
         s = self.export(x_local, self.win, self.plan.hop, self.plan.frames, self.plan.own_samples)
         is_t = isinstance(s, torch.Tensor)
         st = s if is_t else torch.from_numpy(np.ascontiguousarray(s, dtype=np.float64))
-        work = dist.all_reduce(st, group=self.group, async_op=True) if self.plan.world > 1 else None
+        work = dist.all_reduce(st, group=self.group, async_op=True) if self.collective else None
         prev, self._pending = self._pending, (st, work, is_t)
         return None if prev is None else self._finish(prev)
 
     def flush(self):
         prev, self._pending = self._pending, None
         return None if prev is None else self._finish(prev)
+
+
+def native_comm_init(group=None, device=None):
+    """Create the library's own RCCL communicator over the ranks of the torch.distributed group (one process per GPU):
+    rank 0 draws the unique id, one broadcast_object_list hands it out, every rank joins.  After this the sharded PSD runs
+    without the host in the loop (NativeWelchPipeline).  Returns (world, rank)."""
+    import torch.distributed as dist
+    from . import engine as E
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    box = [E.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    E.comm_init(box[0], world, rank, device)
+    return world, rank
+
+
+class NativeWelchPipeline(object):
+    """WelchPipeline with the whole step inside libspectral (sp_welch_dist_submit / sp_welch_dist_flush): export kernels,
+    ncclAllReduce on the library's collective stream behind an event, and the apply of the previous step behind that step's
+    event -- one ctypes call per step, no torch.distributed work object, no host synchronisation (host cost per step ~25 us
+    against ~75-100 us for the torch.distributed form: at 2^25 samples per GPU the kernels of a step take ~0.09 ms, so the
+    Python form is host-bound there).  Needs native_comm_init.  Same interface as WelchPipeline."""
+
+    def __init__(self, win, plan, scale=1.0, sided=2):
+        self.win, self.plan, self.scale, self.sided = win, plan, scale, sided
+        self._dev = None
+
+    def submit(self, x_local):
+        from . import engine as E
+        self._dev = x_local.device
+        p = self.plan
+        return E.welch_dist_submit(x_local, self.win, p.hop, p.frames, p.own_samples, p.frames_total, self.sided, self.scale)
+
+    def flush(self):
+        from . import engine as E
+        if self._dev is None:
+            return None
+        return E.welch_dist_flush(self.plan.nfft, self.sided, self._dev)
 
 
 def welch_psd_sharded_two_step(x_local, win, plan, scale=1.0, sided=2, group=None):
@@ -140,17 +180,23 @@ def _hermitian_unpack(tri, iu, nch, dtype):
     return g
 
 
-def csd_matrix_sharded(x_local, win, plan, scale=1.0, group=None, backend=None, compact=True):
+def csd_matrix_sharded(x_local, win, plan, scale=1.0, group=None, backend=None, compact=None, force_collective=False):
     """Full CSD matrix (BASELINE cfg5) of a long multi-channel record from this rank's frame shard x_local[nch,
     plan.nsamples] (same ShardPlan as the PSD: contiguous frame ranges + halo).  Every channel is detrended with the
     mean of the WHOLE record: all_reduce(nch doubles) of the shard sample sums first, then each rank contracts its
     frames and the accumulator -- the only large exchange of the scope -- is summed with one all_reduce.
-    compact=True (default) sends only the Hermitian upper triangle in complex64: (nfft/2+1) nch (nch+1)/2 x 8 B, 34 MB at
+    compact=True sends only the Hermitian upper triangle in complex64: (nfft/2+1) nch (nch+1)/2 x 8 B, 34 MB at
     cfg5 instead of the 134 MB of the full complex128 matrix (xGMI ring all-reduce is per-link bound, so the bytes are
-    the time); every shard's matrix is float32-accurate anyway and at most `world` such terms are added.
-    compact=False reduces the full complex128 matrix.  `backend` = (means, matrix) callables; default: the HIP kernels."""
+    the time); the HIP kernels' matrix is float32-accurate anyway and at most `world` such terms are added, so the
+    returned complex128 tensor carries float32 content (~6e-8 relative per term) whatever the world size.
+    compact=False reduces the full complex128 matrix.  compact=None (default): True for the HIP kernels, False when a
+    `backend` is supplied (a float64 backend must not lose precision silently).  `backend` = (means, matrix) callables;
+    default: the HIP kernels.  force_collective: issue the collectives in a process group of one rank too."""
     import torch
     import torch.distributed as dist
+    if compact is None:
+        compact = backend is None
+    coll = plan.world > 1 or force_collective
     if backend is None:
         from . import engine as E
         means_fn = lambda x, n: E.channel_means(x, n)                                           # noqa: E731
@@ -160,14 +206,14 @@ def csd_matrix_sharded(x_local, win, plan, scale=1.0, group=None, backend=None, 
     m = means_fn(x_local, plan.own_samples)                       # mean over the samples this rank owns
     is_t = isinstance(m, torch.Tensor)
     st = (m if is_t else torch.from_numpy(np.asarray(m, dtype=np.float64))) * float(plan.own_samples)
-    if plan.world > 1:
+    if coll:
         dist.all_reduce(st, group=group)
     gmean = st / float(plan.total_samples)
     # local contraction normalised by the frames of the whole record, so that the shard results simply add
     g = matrix_fn(x_local, win, plan.hop, plan.frames, gmean if is_t else gmean.numpy(),
                   scale * float(plan.frames) / float(plan.frames_total))
     gt = g if isinstance(g, torch.Tensor) else torch.from_numpy(np.asarray(g, dtype=np.complex128))
-    if plan.world > 1:
+    if coll:
         if compact and gt.is_complex() and gt.dim() == 3:
             tri, iu = _hermitian_pack(gt, torch.complex64)
             dist.all_reduce(torch.view_as_real(tri), group=group)

@@ -224,6 +224,54 @@ def welch_apply(state, win, frames_total, sided=SIDED_TWO, scale=1.0):
     return out
 
 
+# ---- multi-GPU inside the library (include/spectral.h: sp_comm_*, sp_welch_dist_*) ------------------------------------
+def comm_unique_id():
+    """rank 0: the RCCL unique id (bytes) every rank passes to comm_init"""
+    buf = (_ffi.C.c_char * 128)()
+    check(lib().sp_comm_unique_id(_ffi.C.cast(buf, _ffi.C.c_void_p)))
+    return bytes(buf.raw)
+
+
+def comm_init(uid, world, rank, device=None):
+    """join the library's own RCCL communicator (collective over all ranks; one process per GPU)"""
+    _ffi.init(-1 if device is None else int(device))
+    buf = (_ffi.C.c_char * 128).from_buffer_copy(uid)
+    check(lib().sp_comm_init(_ffi.C.cast(buf, _ffi.C.c_void_p), int(world), int(rank)))
+
+
+def comm_info():
+    out = (_ffi.C.c_int * 2)()
+    check(lib().sp_comm_info(out))
+    return int(out[0]), int(out[1])
+
+
+def comm_destroy():
+    check(lib().sp_comm_destroy())
+
+
+def welch_dist_submit(x, win, hop, nframes, nmean, frames_total, sided=SIDED_TWO, scale=1.0):
+    """One step of the sharded Welch PSD with the host out of the loop (sp_welch_dist_submit): this shard's export kernels,
+    the RCCL all-reduce of its state on the library's collective stream, and the apply of the PREVIOUS submit.  x: device
+    tensor (this rank's shard).  Returns the previous step's PSD of the whole stream (float64 [nbins], device) or None."""
+    w = _win32(win)
+    _bind_stream(x)
+    xs = _torch_samples(x)
+    out = torch.empty(nbins(w.size, sided), dtype=torch.float64, device=xs.device)
+    have = _ffi.C.c_int(0)
+    check(lib().sp_welch_dist_submit(ptr(xs.data_ptr()), _tcode(xs), xs.numel(), ptr(w), w.size, int(hop), int(nframes),
+                                     int(nmean), int(frames_total), sided, float(scale), ptr(out.data_ptr()),
+                                     _ffi.C.byref(have), 1))
+    return out if have.value else None
+
+
+def welch_dist_flush(nfft, sided, device):
+    """finish the last welch_dist_submit: its PSD (device tensor) or None when nothing is pending"""
+    out = torch.empty(nbins(nfft, sided), dtype=torch.float64, device=device)
+    have = _ffi.C.c_int(0)
+    check(lib().sp_welch_dist_flush(ptr(out.data_ptr()), _ffi.C.byref(have), 1))
+    return out if have.value else None
+
+
 def welch_finish(nfft, mean, frames_total, sided=SIDED_TWO, scale=1.0, like=None):
     """Second half: apply the (global) mean -- (2,) float64 [re, im], same kind of array welch_accum returned, or None
     for the shard's own mean -- and return scale/frames_total * sum_{local frames} |X|^2 as float64 [nbins]."""

@@ -127,9 +127,12 @@ def _csd_worker(rank, world, port, nch, total, nfft, hop, out_dir):
     x_local = x[:, plan.first_sample: plan.first_sample + plan.nsamples]
     g = csd_matrix_sharded(x_local, win, plan, scale=1.0, backend=_oracle_csd_backend(nfft), compact=False)
     np.save(os.path.join(out_dir, "g%d.npy" % rank), g)
-    # default: only the Hermitian upper triangle travels, in complex64 (34 MB instead of 134 MB at cfg5)
-    gc = csd_matrix_sharded(x_local, win, plan, scale=1.0, backend=_oracle_csd_backend(nfft))
+    # compact: only the Hermitian upper triangle travels, in complex64 (34 MB instead of 134 MB at cfg5)
+    gc = csd_matrix_sharded(x_local, win, plan, scale=1.0, backend=_oracle_csd_backend(nfft), compact=True)
     np.save(os.path.join(out_dir, "gc%d.npy" % rank), gc)
+    # default with a caller-supplied (float64) backend: the full-precision exchange (no silent float32)
+    gd = csd_matrix_sharded(x_local, win, plan, scale=1.0, backend=_oracle_csd_backend(nfft))
+    np.save(os.path.join(out_dir, "gd%d.npy" % rank), gd)
     dist.destroy_process_group()
 
 
@@ -149,6 +152,8 @@ def test_sharded_csd_matrix_matches_single_process(tmp_path, world):
         assert gc.dtype == np.complex128 and gc.shape == ref.shape
         assert np.max(np.abs(gc - ref)) <= 5e-7 * np.abs(ref).max()            # float32 exchange
         assert np.max(np.abs(gc - np.conj(np.swapaxes(gc, 1, 2)))) <= 1e-7 * np.abs(ref).max()   # Hermitian by construction
+        gd = np.load(os.path.join(str(tmp_path), "gd%d.npy" % r))
+        assert np.max(np.abs(gd - ref)) <= 1e-10 * np.abs(ref).max()
 
 
 def _chan_worker(rank, world, port, nch, total, nfft, hop, out_dir):
@@ -253,6 +258,8 @@ def test_bench_self_launch_dryrun():
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["dryrun"] and d["n_gpus"] == 2 and d["rank_sum"] == 3.0 and d["steps"] == 3
+    # the strong-scaling split of the 2^28-sample stream deals out every frame exactly once
+    assert d["strong_frames_total"] == (2 ** 28 - 4096) // 2048 + 1 == d["strong_frames_sum"]
     # a failing child makes the parent exit non-zero
     env["SP_BENCH_DRYRUN"] = "0"
     env["CUDA_VISIBLE_DEVICES"] = ""
