@@ -1995,211 +1995,332 @@ static __global__ void k_cog_finish_op(const cf *__restrict__ acc, int wpf, int6
 // k_op_colsums + k_op_finish are two launches, the second one a single workgroup running a chain of memory round trips and a
 // transform: 7 + 19 us of kernels and two boundaries per step, a third of a 2^25-sample shard's step (strong scaling at 8
 // GPUs).  The transform B = FFT(w c) = sum_g X_g is only needed where W = FFT(window) is non-zero, P[k] = A[k] -
-// 2 Re(conj(d W[k]) B[k]) + M |d W[k]|^2: for the periodic cosine-sum windows (Hann, Hamming, Blackman, Nuttall, the flat-top
-// family: everything the reference's windows() builds but Kaiser / Chebyshev) these are the bins ks = -K .. K, K <= 3 (CogLobe,
-// float64 from the host, checked by Parseval) -- 2K + 1 direct sums over n instead of a transform.  So: the column-sum grid
-// (same blocks, same order of additions as k_op_colsums: bit-identical A and Sl), a release fence + ticket per block, and the
-// block that arrives last (no spinning: nothing waits for another block) finishes: exact mean from the block sums, c[n], the
-// lobe bins of B in float64, and the spectrum / the additive shard state.  `ticket` is zero on entry and is left zero.
+// 2 Re(conj(d W[k]) B[k]) + M |d W[k]|^2: for the periodic cosine-sum windows (Hann, Hamming, Blackman ...) these are the
+// bins ks = -K .. K, K <= 3 (CogLobe, float64 from the host, checked by Parseval) -- 2K + 1 direct sums over n instead of a
+// transform.  So: a column-sum grid (16-byte loads, every load of a thread in flight at once), the sums published with
+// write-through (sc1) stores and a ticket per block, and the block that arrives last (no spinning: nothing waits for another
+// block) finishes from sc1 loads -- the hand-off form of MI355X_MICROARCH.md "Valid forms": sc1 stores drained by the storing
+// wave, ONE lane's agent-scope atomic add, the last adder's block loads behind a workgroup barrier; no release / acquire
+// fence (1.7-6.5 us each).  The last block issues everything it needs in ONE round trip (block sums, raw sums, window, the
+// edge blocks of c[n]), reduces the mean's total and the 2K + 1 lobe sums in ONE block reduction, and writes the spectrum or
+// the additive shard state; its twiddles e^{-2 pi i n / N} are computed before the ticket, off the critical path.
+// `ticket` is zero on entry and is left zero.
 // EXPORT: out = the state of k_op_finish<EXPORT> (A | B | conj(mu0) B | scalars) with B zero outside the lobe bins, which is
-// all k_op_apply multiplies by a non-zero W.
+// all k_op_apply multiplies by a non-zero W.  prev != null (EXPORT): the last block also turns the all-reduced state of the
+// PREVIOUS step into that step's spectrum (k_op_apply's arithmetic; pipelined sharded PSD, sp_welch_dist_submit).
 __device__ __forceinline__ double wave_sum64d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
-template <bool CPLX, bool EXPORT>
-static __global__ __launch_bounds__(1024) void k_op_fused(const float *__restrict__ m0, int N, double *__restrict__ Acol,
-                                                           const float *__restrict__ m1, int H, double *__restrict__ Sl,
-                                                           int64_t G, unsigned *__restrict__ ticket,
-                                                           const void *__restrict__ x, const float *__restrict__ trend,
-                                                           const float *__restrict__ win, CogLobe lb,
-                                                           const double *__restrict__ mean_in, int64_t M, int64_t nmean,
-                                                           int sided, double scale, double *__restrict__ out, int sym) {
-    __shared__ double sh[32][32];
+// SP_OPF_VARIANT (diagnostic builds): bit 0: the ticket is reset with a plain store; bit 1: plain stores / loads with agent-scope
+// release / acquire fences instead of the sc1 forms
+#ifndef SP_OPF_VARIANT
+#define SP_OPF_VARIANT 1
+#endif
+__device__ __forceinline__ void st_sc1(double *p, double v) {
+    if constexpr (SP_OPF_VARIANT & 2) *p = v;
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double *p) {
+    if constexpr (SP_OPF_VARIANT & 2) return *p;
+    else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#if SP_OPF_VARIANT & 4
+__device__ unsigned long long g_opf_t0[1024], g_opf_t1[1024];
+__device__ unsigned g_opf_launches;
+#define OPF_STAMP(v) const unsigned long long v = __builtin_amdgcn_s_memrealtime()
+#else
+#define OPF_STAMP(v)
+#endif
+struct OpPrev {                 // the previous step of the pipelined sharded PSD (all pointers null: nothing to apply)
+    const double *st;           // its all-reduced state [5 N + 8]
+    const cf *Wf;               // FFT(window) (float), N bins
+    double *out;                // its spectrum
+    int sided;
+    double scale;
+};
+// E = edge blocks of c[n] per side: 1 for hop = N/2 and hop = N, 3 for hop = N/4.  512 threads (256 VGPRs: the last block keeps
+// eight bins per thread in flight; at 1024 threads / 128 VGPRs the same code spilled 450 registers and ran 5x slower).
+#define SP_OPF_WG 512
+template <bool CPLX, bool EXPORT, int E>
+static __global__ __launch_bounds__(SP_OPF_WG) void k_op_fused(const float *__restrict__ m0, int N, double *__restrict__ Acol,
+                                                                const float *__restrict__ m1, int H, double *__restrict__ Sl,
+                                                                int64_t G, unsigned *__restrict__ ticket,
+                                                                const void *__restrict__ x, const float *__restrict__ trend,
+                                                                const float *__restrict__ win, CogLobe lb,
+                                                                const double *__restrict__ mean_in, int64_t M, int64_t nmean,
+                                                                int sided, double scale, double *__restrict__ out, int sym,
+                                                                OpPrev prev, double step_c, double step_s) {
+    constexpr int WG = SP_OPF_WG, NW = WG / 64, NSL = WG / 8;
+    OPF_STAMP(ts_start);
+    __shared__ double sh[NW][32];
+    __shared__ double tot_sh[16];
     __shared__ int last_flag;
-    {   // ---- phase 1: k_op_colsums' body (columns of m0 [G][N] -> Acol, of m1 [G][2H] -> Sl)
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    {   // ---- phase 1: column sums of m0 [G][N] -> Acol and of m1 [G][2H] -> Sl.  A block owns 32 columns = 8 lanes of float4;
+        // its NSL row slices: 8 per wave (summed by shuffles), NW waves (summed through LDS); 4 loads per thread in flight
         const int c0 = N, c1 = 2 * H;
-        const int nb0 = (c0 + 31) / 32;
+        const int nb0 = c0 / 32;
         const bool second = (int)blockIdx.x >= nb0;
         const float *__restrict__ m = second ? m1 : m0;
         const int cols = second ? c1 : c0;
         double *__restrict__ o = second ? Sl : Acol;
-        const int lane = threadIdx.x % 32, sl = threadIdx.x / 32;
-        const int k = ((int)blockIdx.x - (second ? nb0 : 0)) * 32 + lane;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        if (k < cols) {
-            int64_t g = sl;
-            for (; g + 96 < G; g += 128) {
-                const float a0 = m[g * cols + k], a1 = m[(g + 32) * cols + k], a2 = m[(g + 64) * cols + k], a3 = m[(g + 96) * cols + k];
-                s0 += (double)a0;
-                s1 += (double)a1;
-                s2 += (double)a2;
-                s3 += (double)a3;
+        const int l8 = threadIdx.x & 7, sl = threadIdx.x >> 3;
+        const int kb = ((int)blockIdx.x - (second ? nb0 : 0)) * 32;
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int64_t g0 = sl; g0 < G; g0 += 4 * NSL) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t g = g0 + NSL * u;
+                v[u] = g < G ? *reinterpret_cast<const float4 *>(m + g * cols + kb + 4 * l8) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            for (; g < G; g += 32) s0 += (double)m[g * cols + k];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s[0] += (double)v[u].x;
+                s[1] += (double)v[u].y;
+                s[2] += (double)v[u].z;
+                s[3] += (double)v[u].w;
+            }
         }
-        sh[sl][lane] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            s[q] += __shfl_xor(s[q], 8);
+            s[q] += __shfl_xor(s[q], 16);
+            s[q] += __shfl_xor(s[q], 32);
+        }
+        if (ln < 8) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sh[wv][4 * ln + q] = s[q];
+        }
         __syncthreads();
-        if (sl == 0 && k < cols) {
+        if (threadIdx.x < 32) {
             double t = 0.0;
 #pragma unroll
-            for (int q = 0; q < 32; ++q) t += sh[q][lane];
-            o[k] = t;
+            for (int w = 0; w < NW; ++w) t += sh[w][threadIdx.x];
+            st_sc1(o + kb + threadIdx.x, t);
         }
     }
-    // ---- hand-off: the stores above all come from wave 0; its lane 0 drains them, releases at agent scope and takes a ticket
+    // ---- hand-off: the sc1 stores above all come from wave 0; it drains them, its lane 0 takes a ticket
+    if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if SP_OPF_VARIANT & 4
+    OPF_STAMP(ts_p1);
     if (threadIdx.x == 0) {
+        __hip_atomic_store(&g_opf_t0[blockIdx.x], ts_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&g_opf_t1[blockIdx.x], ts_p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == gridDim.x - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+#endif
+    if (threadIdx.x == 0) {
+        if constexpr (SP_OPF_VARIANT & 2) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        // two levels (256 adds on one word take 3 us): the blocks with equal blockIdx % 8 share a counter (64 bytes apart), the
+        // last arriver of each group adds to the top counter, the last of those is the last block of the grid
+        const unsigned grp = blockIdx.x & 7u, ngrp = gridDim.x < 8u ? gridDim.x : 8u;
+        const unsigned members = (gridDim.x - 1u - grp) / 8u + 1u;
+        int last = 0;
+        if (__hip_atomic_fetch_add(ticket + 16 * grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u)
+            last = __hip_atomic_fetch_add(ticket + 16 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1u;
         last_flag = last;
+        if constexpr (SP_OPF_VARIANT & 2) {
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
     }
     __syncthreads();
     if (!last_flag) return;
-    // ---- phase 2 (the last block to arrive; every Acol / Sl value is visible now)
-    double *red = &sh[0][0];                   // 16 waves x up to 16 values
-    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    OPF_STAMP(ts_tick);
+#if SP_OPF_VARIANT & 4
+    unsigned long long ts_loaded = 0;
+#endif
+    // ---- phase 2 (the last block to arrive; Acol / Sl are read with sc1 loads only)
     const cf mu = mk(trend[0], trend[1]);
-    const int r = N / H;
-    const int64_t head = (int64_t)(r - 1) * H, cov = (M + r - 1) * (int64_t)H;
-    double tot_r = 0.0, tot_i = 0.0, dr, di;
+    const int hs = __builtin_ctz((unsigned)H);                 // H is a power of two on this path (launch_op_fused checks)
+    const int r = N >> hs;
+    const int64_t cov = (M + r - 1) * (int64_t)H;
+    // 16 sums of ONE block reduction: [0,1] sum_{i < nmean} (x[i] - mu0), [2 + 2 q, 3 + 2 q] B[ks = q - 3]
+    double acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0;
+    if (EXPORT || !mean_in) {         // the ragged end (nothing for a whole signal, one hop for a shard)
+        const int64_t lo = nmean > cov ? cov : nmean, hi = nmean > cov ? nmean : cov;
+        const double sgn = nmean > cov ? 1.0 : -1.0;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += WG) {
+            const cf v = load_sample(x, i, CPLX) - mu;
+            acc[0] += sgn * v.x;
+            acc[1] += sgn * v.y;
+        }
+    }
+    constexpr int NPT = (E > 1 && CPLX) ? 4 : 8;    // bins per thread and chunk: N <= 4096 is one chunk, one round trip (hop = N/4, complex: two)
+    double ak[NPT];                                 // raw sums A[k] of the thread's bins (kept for the output loop)
+    // uniform bases + 32-bit lane offsets (scalar-base addressing: one offset register per load instead of a 64-bit address)
+    const char *xh = reinterpret_cast<const char *>(x), *xt = xh + M * (int64_t)H * (CPLX ? 8 : 4);
+    for (int base = 0; base < N; base += WG * NPT) {
+        double slr[NPT], sli[NPT];
+        float wn[NPT];
+        cf eh[NPT][E], et[NPT][E];
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) {
+            const unsigned nidx = (unsigned)(base + (int)threadIdx.x + WG * t);
+            const bool on = nidx < (unsigned)N;
+            const unsigned nc = on ? nidx : 0u;
+            const unsigned q = nc >> hs, j = nc & (unsigned)(H - 1);
+            slr[t] = ld_sc1(Sl + 2u * j);
+            sli[t] = ld_sc1(Sl + 2u * j + 1u);
+            ak[t] = ld_sc1(Acol + nc);
+            wn[t] = win[nc];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {           // edge blocks of c[n]: b = q + e <= r - 2 (head), b = M + q + e <= M + r - 2 (tail)
+                const bool he = on && (int)q + e <= r - 2;
+                const unsigned off = he ? ((q + (unsigned)e) << hs) + j : 0u;
+                const cf vh = load_sample(xh, off, CPLX), vt = load_sample(xt, off, CPLX);
+                eh[t][e] = he ? vh - mu : mk(0.f, 0.f);
+                et[t][e] = he ? vt - mu : mk(0.f, 0.f);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);          // (all loads issued above; consumed one bin at a time below)
+#if SP_OPF_VARIANT & 4
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#if SP_OPF_VARIANT & 4
+        ts_loaded = __builtin_amdgcn_s_memrealtime();
+#endif
+        // e^{-i theta_n}, theta_n = 2 pi n / N, for n = base + tid, then rotated by the step e^{-2 pi i WG / N} from bin to bin
+        double c1, s1;
+        sincospi(-2.0 * (double)(base + (int)threadIdx.x) / (double)N, &s1, &c1);
+#pragma unroll
+        for (int t = 0; t < NPT; ++t) {
+            const int nidx = base + (int)threadIdx.x + WG * t;
+            if (nidx < N) {
+                const int q = nidx >> hs;
+                double a = slr[t], b = sli[t];
+                if (q == 0) {                     // every j once: the block sums, and below the head blocks i < (r - 1) H
+                    acc[0] += a;
+                    acc[1] += b;
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (q == 0) {
+                        acc[0] += (double)eh[t][e].x;
+                        acc[1] += (double)eh[t][e].y;
+                    }
+                    a += (double)eh[t][e].x - (double)et[t][e].x;
+                    b += (double)eh[t][e].y - (double)et[t][e].y;
+                }
+                a *= (double)wn[t];
+                b *= (double)wn[t];
+                acc[2 + 6] += a;
+                acc[3 + 6] += b;
+                double pr = 1.0, pi_ = 0.0;
+#pragma unroll
+                for (int ks = 1; ks <= 3; ++ks) {
+                    const double tr_ = pr * c1 - pi_ * s1, ti_ = pr * s1 + pi_ * c1;      // e^{-i ks theta}
+                    pr = tr_;
+                    pi_ = ti_;
+                    acc[2 + 2 * (3 + ks)] += a * pr - b * pi_;
+                    acc[3 + 2 * (3 + ks)] += a * pi_ + b * pr;
+                    acc[2 + 2 * (3 - ks)] += a * pr + b * pi_;                          // the conjugate phase for -ks
+                    acc[3 + 2 * (3 - ks)] += b * pr - a * pi_;
+                }
+            }
+            const double nc1 = c1 * step_c - s1 * step_s, ns1 = c1 * step_s + s1 * step_c;
+            c1 = nc1;
+            s1 = ns1;
+        }
+    }
+    OPF_STAMP(ts_math);
+    // across the wave: the mean's total in double (shuffles), the lobe sums in float through DPP (no LDS round trips; they enter
+    // the spectrum multiplied by d = mean - mu0: float32 is ample); across the waves: LDS
+    acc[0] = wave_sum64d(acc[0]);
+    acc[1] = wave_sum64d(acc[1]);
+#pragma unroll
+    for (int q = 2; q < 16; ++q) acc[q] = (double)wave_sum64((float)acc[q]);
+    __syncthreads();                               // (phase 1's use of sh is over in every wave)
+    if (ln == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sh[wv][q] = acc[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a += sh[w][threadIdx.x];
+        tot_sh[threadIdx.x] = a;
+    }
+    __syncthreads();
+    const double tot_r = tot_sh[0], tot_i = tot_sh[1];
+    double dr, di;
     if (!EXPORT && mean_in) {
         dr = mean_in[0] - (double)trend[0];
         di = mean_in[1] - (double)trend[1];
     } else {
-        // sum_{i < nmean} (x[i] - mu0) = all block sums + the head blocks -/+ the ragged end (as k_op_finish)
-        double a = 0.0, b = 0.0;
-        for (int j = threadIdx.x; j < H; j += 1024) {
-            a += Sl[2 * j];
-            b += Sl[2 * j + 1];
-        }
-        for (int64_t i = threadIdx.x; i < head; i += 1024) {
-            const cf v = load_sample(x, i, CPLX);
-            a += (double)(v.x - mu.x);
-            b += (double)(v.y - mu.y);
-        }
-        const int64_t lo = nmean > cov ? cov : nmean, hi = nmean > cov ? nmean : cov;
-        const double sgn = nmean > cov ? 1.0 : -1.0;
-        for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) {
-            const cf v = load_sample(x, i, CPLX) - mu;
-            a += sgn * v.x;
-            b += sgn * v.y;
-        }
-        a = wave_sum64d(a);
-        b = wave_sum64d(b);
-        __syncthreads();
-        if (ln == 0) {
-            red[2 * wv] = a;
-            red[2 * wv + 1] = b;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            tot_r += red[2 * w];
-            tot_i += red[2 * w + 1];
-        }
         dr = tot_r / (double)nmean;
         di = tot_i / (double)nmean;
     }
-    // B[ks] = sum_n w[n] c[n] e^{-2 pi i ks n / N}, ks = -3 .. 3, c[n] = sum_g x_g[n] rebuilt from the block sums and the edge blocks
-    double br[7], bi[7];
-#pragma unroll
-    for (int q = 0; q < 7; ++q) br[q] = bi[q] = 0.0;
-    for (int nidx = threadIdx.x; nidx < N; nidx += 1024) {
-        const int q = nidx / H, j = nidx % H;
-        double a = Sl[2 * j], b = Sl[2 * j + 1];
-        for (int bb = q; bb <= r - 2; ++bb) {
-            const cf v = load_sample(x, (int64_t)bb * H + j, CPLX) - mu;
-            a += v.x;
-            b += v.y;
-        }
-        for (int64_t bb = M + q; bb <= M + r - 2; ++bb) {
-            const cf v = load_sample(x, bb * H + j, CPLX) - mu;
-            a -= v.x;
-            b -= v.y;
-        }
-        const double wn = (double)win[nidx];
-        a *= wn;
-        b *= wn;
-        double s1, c1;
-        sincospi(-2.0 * (double)nidx / (double)N, &s1, &c1);          // e^{-i theta}, theta = 2 pi n / N
-        br[3] += a;
-        bi[3] += b;
-        double pr = 1.0, pi_ = 0.0;
-#pragma unroll
-        for (int ks = 1; ks <= 3; ++ks) {
-            const double tr_ = pr * c1 - pi_ * s1, ti_ = pr * s1 + pi_ * c1;      // e^{-i ks theta}
-            pr = tr_;
-            pi_ = ti_;
-            br[3 + ks] += a * pr - b * pi_;
-            bi[3 + ks] += a * pi_ + b * pr;
-            br[3 - ks] += a * pr + b * pi_;                                     // conj phase for -ks
-            bi[3 - ks] += b * pr - a * pi_;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < 7; ++q) {
-        br[q] = wave_sum64d(br[q]);
-        bi[q] = wave_sum64d(bi[q]);
-    }
-    __syncthreads();
-    if (ln == 0) {
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            red[16 * wv + 2 * q] = br[q];
-            red[16 * wv + 2 * q + 1] = bi[q];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 7; ++q) {
-        double a = 0.0, b = 0.0;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) {
-            a += red[16 * w + 2 * q];
-            b += red[16 * w + 2 * q + 1];
-        }
-        br[q] = a;
-        bi[q] = b;
-    }
+    OPF_STAMP(ts_red);
     const double mr = (double)mu.x, mi = (double)mu.y;
-    for (int k = threadIdx.x; k < N; k += 1024) {
-        const double a = sym ? 0.5 * (Acol[k] + Acol[(N - k) & (N - 1)]) : Acol[k];
-        const int ks = k <= lb.K ? k : (k >= N - lb.K ? k - N : 99);
-        const bool in = ks != 99;
-        double Br = 0.0, Bi = 0.0, wr = 0.0, wi = 0.0;
-        if (in) {
+    const bool one_chunk = N <= WG * NPT;
+    for (int base = 0; base < N; base += WG * NPT) {
 #pragma unroll
-            for (int q = 0; q < 7; ++q)
-                if (q == ks + 3) {
-                    Br = br[q];
-                    Bi = bi[q];
-                    wr = lb.wr[q];
-                    wi = lb.wi[q];
+        for (int t = 0; t < NPT; ++t) {
+            const int k = base + (int)threadIdx.x + WG * t;
+            if (k >= N) continue;
+            double a = one_chunk ? ak[t] : ld_sc1(Acol + k);
+            if (sym) a = 0.5 * (a + ld_sc1(Acol + ((N - k) & (N - 1))));          // real-pair transforms: |Z|^2 symmetrised
+            const int ks = k <= lb.K ? k : (k >= N - lb.K ? k - N : 99);
+            double Br = 0.0, Bi = 0.0, wr = 0.0, wi = 0.0;
+            if (ks != 99) {                                                      // (2 K + 1 bins of the whole block)
+                Br = tot_sh[2 + 2 * (ks + 3)];
+                Bi = tot_sh[3 + 2 * (ks + 3)];
+#pragma unroll
+                for (int u = 0; u < 7; ++u)
+                    if (u == ks + 3) {
+                        wr = lb.wr[u];
+                        wi = lb.wi[u];
+                    }
+            }
+            if constexpr (EXPORT) {
+                out[k] = a;
+                out[N + 2 * k] = Br;
+                out[N + 2 * k + 1] = Bi;
+                out[3 * N + 2 * k] = mr * Br + mi * Bi;          // conj(mu0) B
+                out[3 * N + 2 * k + 1] = mr * Bi - mi * Br;
+            } else {
+                const int slot = bin_slot(k, N, sided);
+                if (slot >= 0) {
+                    const double er = dr * wr - di * wi, ei = dr * wi + di * wr;       // d W[k]
+                    const double p = a - 2.0 * (er * Br + ei * Bi) + (double)M * (er * er + ei * ei);
+                    out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
                 }
-        }
-        if constexpr (EXPORT) {
-            out[k] = a;
-            out[N + 2 * k] = Br;
-            out[N + 2 * k + 1] = Bi;
-            out[3 * N + 2 * k] = mr * Br + mi * Bi;          // conj(mu0) B
-            out[3 * N + 2 * k + 1] = mr * Bi - mi * Br;
-        } else {
-            const int slot = bin_slot(k, N, sided);
-            if (slot >= 0) {
-                const double er = dr * wr - di * wi, ei = dr * wi + di * wr;       // d W[k]
-                const double p = a - 2.0 * (er * Br + ei * Bi) + (double)M * (er * er + ei * ei);
-                out[slot] = p * scale * (bin_doubled(k, N, sided) ? 2.0 : 1.0);
             }
         }
     }
+#if SP_OPF_VARIANT & 4
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        OPF_STAMP(ts_end);
+        const unsigned nl = g_opf_launches++;
+        if (nl % 50 == 49) {
+            unsigned long long tmin = ~0ull, tmax0 = 0, tmax1 = 0;
+            for (unsigned b = 0; b < gridDim.x; ++b) {
+                const unsigned long long a0 = __hip_atomic_load(&g_opf_t0[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long a1 = __hip_atomic_load(&g_opf_t1[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tmin = a0 < tmin ? a0 : tmin;
+                tmax0 = a0 > tmax0 ? a0 : tmax0;
+                tmax1 = a1 > tmax1 ? a1 : tmax1;
+            }
+            // 100 MHz ticks -> ns x 10
+            printf("opf stamps (x10 ns from the first block's start): last block start %llu | all phase-1 done %llu | ticket known %llu | "
+                   "loads landed %llu | math %llu | reduced %llu | end %llu\n", tmax0 - tmin, tmax1 - tmin, ts_tick - tmin,
+                   ts_loaded - tmin, ts_math - tmin, ts_red - tmin, ts_end - tmin);
+        }
+    }
+#endif
     if (threadIdx.x == 0) {
         if constexpr (EXPORT) {
             double *sc = out + 5 * (int64_t)N;
@@ -2212,7 +2333,26 @@ static __global__ __launch_bounds__(1024) void k_op_fused(const float *__restric
             sc[6] = (double)nmean;
             sc[7] = 0.0;
         }
-        *ticket = 0u;                       // ready for the next launch (ordered by the kernel boundary)
+        // ready for the next launch (plain stores: the atomic form cost 1.6 us at the kernel boundary)
+    }
+    if (threadIdx.x < 9) ticket[16 * threadIdx.x] = 0u;
+    if constexpr (EXPORT) {
+        if (prev.st) {          // k_op_apply's arithmetic on the previous step's summed state (same N)
+            const double *st = prev.st;
+            const double *sc = st + 5 * (int64_t)N;
+            const double Mt = sc[5], nt = sc[6];
+            const double gr = sc[3] / nt, gi = sc[4] / nt;
+            const double sq = (gr * gr + gi * gi) * Mt - 2.0 * (gr * sc[0] + gi * sc[1]) + sc[2];
+            for (int k = threadIdx.x; k < N; k += WG) {
+                const int slot = bin_slot(k, N, prev.sided);
+                if (slot < 0) continue;
+                const double b_r = st[N + 2 * k], b_i = st[N + 2 * k + 1], cr = st[3 * N + 2 * k], ci = st[3 * N + 2 * k + 1];
+                const double d_r = gr * b_r + gi * b_i - cr, d_i = gr * b_i - gi * b_r - ci;            // conj(mu) B - C
+                const double wr = prev.Wf[k].x, wi = prev.Wf[k].y;
+                const double p = st[k] - 2.0 * (wr * d_r + wi * d_i) + (wr * wr + wi * wi) * sq;
+                prev.out[slot] = p * prev.scale * (bin_doubled(k, N, prev.sided) ? 2.0 : 1.0);
+            }
+        }
     }
 }
 

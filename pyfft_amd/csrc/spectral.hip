@@ -685,11 +685,15 @@ struct FusedOut {
     double scale;          // already divided by the frame count
     double *out;
     bool done;
+    // pipelined sharded PSD: the previous step's summed state, applied by the same launch behind `prev_wait` (its all-reduce)
+    OpPrev prev = OpPrev{nullptr, nullptr, nullptr, 0, 0.0};
+    hipEvent_t prev_wait = nullptr;
+    bool prev_done = false;
 };
 unsigned *get_ticket() {
-    if (!g.ticket.p) {
-        if (g.ticket.ensure(256)) return nullptr;
-        if (hipMemset(g.ticket.p, 0, 256) != hipSuccess) return nullptr;
+    if (!g.ticket.p) {                  // 9 counters, 64 bytes apart (k_op_fused)
+        if (g.ticket.ensure(1024)) return nullptr;
+        if (hipMemset(g.ticket.p, 0, 1024) != hipSuccess) return nullptr;
     }
     return (unsigned *)g.ticket.p;
 }
@@ -759,9 +763,11 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     if (fo && !want_sum && !env_flag("SP_OP_UNFUSED") && cog_window_lobe(win, nfft, &lobe)) {
         unsigned *ticket = get_ticket();
         if (!ticket) return fail("ticket allocation failed");
+        if (fo->prev.st && fo->prev_wait) HIPCHK(hipStreamWaitEvent(g.stream, fo->prev_wait, 0));
         LAUNCHCHK(launch_op_fused(lc(), xd, cplx, tb.f, (const float *)win_d, partial, spartial, rp.groups, nfft, hop, nframes, nmean,
-                                  st, ticket, lobe, nullptr, fo->sided, fo->scale, fo->out, fo->export_state));
+                                  st, ticket, lobe, nullptr, fo->sided, fo->scale, fo->out, fo->export_state, fo->prev));
         fo->done = true;
+        fo->prev_done = fo->prev.st != nullptr;
         g_pend.valid = false;
         return 0;
     }
@@ -865,10 +871,16 @@ int dist_apply_locked(int s, double *out_d) {
 
 // this shard's additive state (sp_welch_export) into st_d (device, 5 nfft + 8 doubles)
 int welch_export_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-                        int64_t nmean, double *st_d) {
+                        int64_t nmean, double *st_d, const OpPrev *prev = nullptr, hipEvent_t prev_wait = nullptr,
+                        bool *prev_done = nullptr) {
     FusedOut fo{true, SP_SIDED_RAW, 1.0, st_d, false};
+    if (prev) {
+        fo.prev = *prev;
+        fo.prev_wait = prev_wait;
+    }
     if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, false, &fo)) return -1;
     g_pend.valid = false;
+    if (prev_done) *prev_done = fo.prev_done;
     if (fo.done) return 0;
     LAUNCHCHK(launch_op_finish(lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, nullptr, g_pend.nmean,
                                g_pend.xf, g_pend.hop, g_pend.nframes, g_pend.cw, g_pend.Wf, SP_SIDED_RAW, 1.0, st_d, true));
@@ -1347,8 +1359,34 @@ int sp_welch_dist_submit(const void *x, int x_dtype, int64_t nsig, const float *
     const size_t nst = 5 * (size_t)nfft + 8;
     if (gcomm.st[s].ensure(sizeof(double) * nst)) return -1;
     double *st_d = (double *)gcomm.st[s].p;
+    // the previous step (its all-reduce has had this step's main kernel to complete): when both steps have the same
+    // transform length, the launch that finishes THIS step's state also applies the previous one (k_op_fused, behind the
+    // collective's event) -- no separate launch
+    DistSlot &po = gcomm.slot[o];
+    const bool have_o = po.valid;
+    double *prev_d = nullptr;
+    int nb_o = 0;
+    OpPrev prev{nullptr, nullptr, nullptr, 0, 0.0};
+    if (have_o) {
+        if (!pxx_prev) return fail("sp_welch_dist_submit: a previous step is pending and pxx_prev is null");
+        nb_o = nbins_host((int)po.win.size(), po.sided);
+        prev_d = pxx_prev;
+        if (!mem) {
+            if (g.out0.ensure(sizeof(double) * (size_t)nb_o)) return -1;
+            prev_d = (double *)g.out0.p;
+        }
+        if ((int)po.win.size() == nfft && !env_flag("SP_DIST_SEPARATE_APPLY")) {
+            Xf xfo;
+            if (get_xf(nfft, &xfo)) return -1;
+            void *Wf_o;
+            if (get_window_spectrum(po.win.data(), nfft, xfo, &Wf_o)) return -1;
+            prev = OpPrev{(const double *)gcomm.st[o].p, (const cf *)Wf_o, prev_d, po.sided, po.scale / (double)po.frames_total};
+        }
+    }
     // this step: the shard's additive state on the launch stream, its all-reduce on the collective's stream behind an event
-    if (welch_export_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, st_d)) return -1;
+    bool prev_done = false;
+    if (welch_export_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, st_d, prev.st ? &prev : nullptr, gcomm.ev_red[o], &prev_done))
+        return -1;
     HIPCHK(hipEventRecord(gcomm.ev_exp[s], g.stream));
     HIPCHK(hipStreamWaitEvent(gcomm.cs, gcomm.ev_exp[s], 0));
     NCCLCHK(rccl.AllReduce(st_d, st_d, nst, ncclDouble, ncclSum, gcomm.comm, gcomm.cs));
@@ -1359,18 +1397,11 @@ int sp_welch_dist_submit(const void *x, int x_dtype, int64_t nsig, const float *
     gcomm.slot[s].sided = sided;
     gcomm.slot[s].scale = scale;
     gcomm.cur = o;
-    // the previous step: its all-reduce has had this step's kernels to complete
-    if (gcomm.slot[o].valid) {
-        if (!pxx_prev) return fail("sp_welch_dist_submit: a previous step is pending and pxx_prev is null");
-        const int nb = nbins_host((int)gcomm.slot[o].win.size(), gcomm.slot[o].sided);
-        double *out_d = pxx_prev;
+    if (have_o) {
+        if (prev_done) po.valid = false;
+        else if (dist_apply_locked(o, prev_d)) return -1;
         if (!mem) {
-            if (g.out0.ensure(sizeof(double) * (size_t)nb)) return -1;
-            out_d = (double *)g.out0.p;
-        }
-        if (dist_apply_locked(o, out_d)) return -1;
-        if (!mem) {
-            HIPCHK(hipMemcpyAsync(pxx_prev, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
+            HIPCHK(hipMemcpyAsync(pxx_prev, prev_d, sizeof(double) * (size_t)nb_o, hipMemcpyDeviceToHost, g.stream));
             HIPCHK(hipStreamSynchronize(g.stream));
         }
         if (have_prev) *have_prev = 1;
