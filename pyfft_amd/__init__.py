@@ -22,3 +22,5 @@ from .notch_filter import iirnotch, iirpeak, apply_notch     # noqa: F401
 from .filters import fftfilt                                 # noqa: F401
 from . import doppler                                        # noqa: F401   (Doppler.cog / cogspec window loop)
 from .doppler import cog, cog_frames                         # noqa: F401
+from . import heatpulse                                      # noqa: F401   (HeatPulse_Funcs._PWELCH_chloop as one call)
+from .heatpulse import pwelch_chloop                         # noqa: F401

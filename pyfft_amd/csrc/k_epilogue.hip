@@ -35,12 +35,41 @@ static __global__ __launch_bounds__(256) void k_epi_elem(const double *__restric
 //   s = 0: Pxx;  1..nch: Pyy_c;  nch+1..2nch: Pxy_c;  2nch+1..3nch: Cxy_c
 // one-sided input (bins [0, nb)): [1:-1] halved (and the last bin when nfft is odd), bins beyond nb zero, then the
 // Hermitian mirror with real DC / Nyquist -- numpy.fft.irfft semantics (:544-577); two-sided input (shifted): ifftshift.
+// The inverse transforms run in float32: every row is divided by a scale of its own first and multiplied back in float64 behind
+// the transform (spectra of a volts-scale 1e-10 signal, P ~ 1e-26, lost their halved bins to float32 denormals; large
+// ones overflowed).  rowmax[s] = max_k of Pxx (s = 0) / Pyy_c (s = 1 + c); scale of Pxx: rowmax[0], Pyy_c: rowmax[1 + c],
+// Pxy_c: sqrt(rowmax[0] rowmax[1 + c]) >= |Pxy_c[k]| (Cauchy-Schwarz bin by bin), the coherence: 1.
+static __global__ __launch_bounds__(256) void k_epi_rowmax(const double *__restrict__ pxx, const double *__restrict__ pyy, int nb,
+                                                            double *__restrict__ rowmax) {
+    __shared__ double sh[256];
+    const int s = blockIdx.x;
+    const double *p = s == 0 ? pxx : pyy + (int64_t)(s - 1) * nb;
+    double m = 0.0;
+    for (int k = threadIdx.x; k < nb; k += 256) m = fmax(m, fabs(p[k]));
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) rowmax[s] = sh[0];
+}
+__device__ __forceinline__ double epi_row_scale(const double *__restrict__ rowmax, int s, int nch) {
+    double v = 1.0;
+    if (s == 0) v = rowmax[0];
+    else if (s <= nch) v = rowmax[s];
+    else if (s <= 2 * nch) v = sqrt(rowmax[0] * rowmax[s - nch]);
+    return v > 0.0 && isfinite(v) ? v : 1.0;
+}
+
 static __global__ __launch_bounds__(256) void k_epi_spec(const double *__restrict__ pxx, const double *__restrict__ pyy,
                                                           const double *__restrict__ pxy, const double *__restrict__ cxy, int nch,
-                                                          int nb, int nfft, int onesided, cf *__restrict__ X) {
+                                                          int nb, int nfft, int onesided, cf *__restrict__ X,
+                                                          const double *__restrict__ rowmax) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int s = blockIdx.y;
     if (j >= nfft) return;
+    const double inv = 1.0 / epi_row_scale(rowmax, s, nch);
     auto value = [&](int k, double &re, double &im) __attribute__((always_inline)) {
         if (s == 0) {
             re = pxx[k];
@@ -77,7 +106,7 @@ static __global__ __launch_bounds__(256) void k_epi_spec(const double *__restric
         if (k >= nfft) k -= nfft;
         value(k, re, im);
     }
-    X[(int64_t)s * nfft + j] = mk((float)re, (float)im);
+    X[(int64_t)s * nfft + j] = mk((float)(re * inv), (float)(im * inv));
 }
 
 // R[s][fftshift slot] = sqrt(nfft) * x[s][j] as float64 pairs (real part only for one-sided input: irfft is real);
@@ -85,11 +114,11 @@ static __global__ __launch_bounds__(256) void k_epi_spec(const double *__restric
 static __global__ __launch_bounds__(256) void k_epi_corr(const cf *__restrict__ X, int nch, int nfft, int onesided,
                                                           double *__restrict__ rxx, double *__restrict__ ryy,
                                                           double *__restrict__ rxy, double *__restrict__ icxy,
-                                                          double *__restrict__ ee) {
+                                                          double *__restrict__ ee, const double *__restrict__ rowmax) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int s = blockIdx.y;
     if (j >= nfft) return;
-    const double sc = sqrt((double)nfft);
+    const double sc = sqrt((double)nfft) * epi_row_scale(rowmax, s, nch);
     const cf v = X[(int64_t)s * nfft + j];
     const double re = sc * (double)v.x, im = onesided ? 0.0 : sc * (double)v.y;
     int slot = j + nfft / 2;
@@ -135,16 +164,17 @@ int launch_epi_elem(LaunchCtx c, const double *pxx, const double *pyy, const dou
     return 0;
 }
 int launch_epi_spec(LaunchCtx c, const double *pxx, const double *pyy, const double *pxy, const double *cxy, int nch, int nb,
-                    int nfft, int onesided, cf *X) {
+                    int nfft, int onesided, cf *X, double *rowmax) {
     if (3 * nch + 1 > 65535) return -1;
+    hipLaunchKernelGGL(k_epi_rowmax, dim3((unsigned)(nch + 1)), dim3(256), 0, c.stream, pxx, pyy, nb, rowmax);
     hipLaunchKernelGGL(k_epi_spec, dim3(blocks_of(nfft), (unsigned)(3 * nch + 1)), dim3(256), 0, c.stream, pxx, pyy, pxy, cxy, nch, nb,
-                       nfft, onesided, X);
+                       nfft, onesided, X, rowmax);
     return 0;
 }
 int launch_epi_corr(LaunchCtx c, const cf *X, int nch, int nfft, int onesided, double *rxx, double *ryy, double *rxy, double *icxy,
-                    double *ee, double *cc) {
+                    double *ee, double *cc, const double *rowmax) {
     hipLaunchKernelGGL(k_epi_corr, dim3(blocks_of(nfft), (unsigned)(3 * nch + 1)), dim3(256), 0, c.stream, X, nch, nfft, onesided, rxx,
-                       ryy, rxy, icxy, ee);
+                       ryy, rxy, icxy, ee, rowmax);
     hipLaunchKernelGGL(k_epi_corrcoef, dim3(blocks_of(nfft), (unsigned)nch), dim3(256), 0, c.stream, (const double *)rxy,
                        (const double *)ee, nch, nfft, cc);
     return 0;

@@ -217,9 +217,9 @@ int launch_biquad(LaunchCtx c, const double *b, const double *a, const float *x,
 int launch_epi_elem(LaunchCtx c, const double *pxx, const double *pyy, const double *pxy, int nch, int nb, int nfft, int onesided,
                     double enbw, double *cxy, double *cxy2, double *phi, double *lxx, double *lyy, double *lxy);
 int launch_epi_spec(LaunchCtx c, const double *pxx, const double *pyy, const double *pxy, const double *cxy, int nch, int nb,
-                    int nfft, int onesided, cf *X);
+                    int nfft, int onesided, cf *X, double *rowmax /* [1 + nch] scratch: the rows' scales */);
 int launch_epi_corr(LaunchCtx c, const cf *X, int nch, int nfft, int onesided, double *rxx, double *ryy, double *rxy, double *icxy,
-                    double *ee, double *cc);
+                    double *ee, double *cc, const double *rowmax);
 
 // dispatch over the transform: MACRO(XTYPE) with XTYPE = XfPow2<L> or XfBlue<L>
 #define SP_CASE_P(Lv, MACRO) case Lv: { MACRO(XfPow2<Lv>) } break;

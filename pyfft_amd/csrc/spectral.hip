@@ -80,7 +80,7 @@ struct Ctx {
     hipStream_t stream = nullptr;
     std::map<int64_t, cf *> twiddles;   // L -> exp(-2 pi i m/L)
     std::map<int64_t, BlueTab> blue;    // n -> Bluestein tables
-    Scratch in0, in1, out0, work, small, trends, onepass, ticket;
+    Scratch in0, in1, out0, work, small, trends, onepass, ticket, epi;
     Scratch pend_trend;                       // trend record a pending sp_welch_accum keeps until sp_welch_finish
     Scratch bigA, bigB, bigT, blueA, blueB, longrec;   // long (multi-kernel) paths
     Scratch cmS, cmT, cmG, cmH, cmO;               // CSD matrix: spectra, bin-major spectra, float64 accumulator, packed-spectra sums, one-pass means state
@@ -702,6 +702,10 @@ unsigned *get_ticket() {
 // derives the shard mean itself
 int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
                        int64_t nmean, bool want_sum, FusedOut *fo = nullptr) {
+    if (!wg_capable(nfft))
+        return fail("sharded / split Welch PSD (sp_welch_accum, sp_welch_export, sp_welch_dist_*): segments longer than one workgroup "
+                    "transform are not sharded (nfft = %d; powers of two in [256, %d] with hop = nfft/4, nfft/2 or nfft) -- the "
+                    "long-segment regime has few, large frames: run sp_welch_psd on one GPU", nfft, SP_MAX_WG_FFT);
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
     if (!welch_carry_eligible(xf, hop, false))
@@ -941,6 +945,7 @@ void sp_shutdown(void) {
     g.trends.release();
     g.onepass.release();
     g.ticket.release();
+    g.epi.release();
     g.pend_trend.release();
     g.cmS.release();
     g.cmT.release();
@@ -1251,6 +1256,9 @@ int sp_welch_apply(const double *state, const float *win, int nfft, int64_t fram
     if (sided < 1 || sided > 3) return fail("sp_welch_apply: bad sided");
     if (frames_total < 1) return fail("sp_welch_apply: frames_total must be positive");
     ApiLock lk;
+    if (!wg_capable(nfft))
+        return fail("sp_welch_apply: segments longer than one workgroup transform are not sharded (nfft = %d, at most %d)", nfft,
+                    SP_MAX_WG_FFT);
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
     if (xf.blue) return fail("sp_welch_apply: power-of-two nfft only");
@@ -2307,11 +2315,13 @@ int sp_csd_epilogue(const double *pxx, const double *pyy, const double *pxy, int
     double *ee = cc + 2 * C * NF;
     LAUNCHCHK(launch_epi_elem(lc(), dxx, dyy, dxy, nch, nb, nfft, onesided, enbw, cxy, cxy2, phi, lxx, lyy, lxy));
     const size_t nsig = 3 * C + 1;
-    if (g.bigA.ensure(sizeof(cf) * nsig * NF)) return -1;
+    if (g.bigA.ensure(sizeof(cf) * nsig * NF) || g.epi.ensure(sizeof(double) * (C + 1))) return -1;
     cf *X = (cf *)g.bigA.p;
-    LAUNCHCHK(launch_epi_spec(lc(), dxx, dyy, dxy, cxy, nch, nb, nfft, onesided, X));
+    // the rows' scales: the inverse transforms run in float32 on rows normalised to O(1) (k_epilogue.hip)
+    double *rowmax = (double *)g.epi.p;
+    LAUNCHCHK(launch_epi_spec(lc(), dxx, dyy, dxy, cxy, nch, nb, nfft, onesided, X, rowmax));
     if (dev_fft_any(X, X, nfft, (int64_t)nsig, 1)) return -1;
-    LAUNCHCHK(launch_epi_corr(lc(), X, nch, nfft, onesided, rxx, ryy, rxy, icxy, ee, cc));
+    LAUNCHCHK(launch_epi_corr(lc(), X, nch, nfft, onesided, rxx, ryy, rxy, icxy, ee, cc, rowmax));
     if (!mem) {
         HIPCHK(hipMemcpyAsync(out, od, sizeof(double) * n_out, hipMemcpyDeviceToHost, g.stream));
         HIPCHK(hipStreamSynchronize(g.stream));
@@ -2328,6 +2338,13 @@ int sp_biquad(const double *b, const double *a, const float *x, int64_t n, float
     if (ensure_init()) return -1;
     if (n < 1 || b == nullptr || a == nullptr) return fail("sp_biquad: bad arguments");
     if (a[0] == 0.0) return fail("sp_biquad: a[0] must not be zero");
+    {   // the blocked scan raises the state map to powers up to n: an unstable section overflows them to inf and inf * 0 = NaN
+        // would reach every output (scipy's lfilter returns the valid early samples) -- refuse instead
+        const double a1 = a[1] / a[0], a2 = a[2] / a[0], disc = a1 * a1 - 4.0 * a2;
+        const double rad = disc < 0.0 ? sqrt(a2) : 0.5 * (fabs(a1) + sqrt(disc));
+        if (!(rad <= 1.0 + 1e-12))
+            return fail("sp_biquad: unstable section (pole radius %.9g > 1): the blocked scan of the state maps does not apply", rad);
+    }
     ApiLock lk;
     const float *xd = x;
     float *yd = y;

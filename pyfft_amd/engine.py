@@ -573,6 +573,10 @@ def biquad_filter(b, a, x):
     aa = np.concatenate([aa, np.zeros(3 - aa.size)])
     if aa[0] == 0.0:
         raise ValueError("biquad_filter: a[0] must not be zero")
+    rts = np.roots(aa)
+    if rts.size and float(np.max(np.abs(rts))) > 1.0 + 1e-12:
+        # (the device scan raises the state map to powers up to len(x): an unstable section would overflow them to inf / NaN)
+        raise ValueError("biquad_filter: unstable section (pole radius %.9g > 1)" % float(np.max(np.abs(rts))))
     if _is_torch(x):
         _bind_stream(x)
         if x.is_complex() or x.dim() != 1:

@@ -936,9 +936,20 @@ class fftanal(Struct):
                 setattr(self, p, np.mean(getattr(self, p + "_seg"), axis=0))
                 setattr(self, "var" + p, (getattr(self, p) / np.sqrt(self.Navr)) ** 2.0)
             self.phi_xy = np.angle(self.Pxy)
+            # the reference's next statement (averagewins -> Cxy_Cxy2, fft_analysis.py:1669) takes np.size(Pyy, axis=1) of the
+            # 1-D means: numpy raises its own exception there (numpy >= 2: AxisError, a subclass of IndexError AND ValueError;
+            # older: IndexError) -- the same call is made here so that `except` clauses behave as with the reference.  The
+            # working half of this branch is public as `scipy_stft()`.
+            self.Cxy, self.Cxy2 = Cxy_Cxy2(self.Pxx, self.Pyy, self.Pxy)
             raise IndexError("tuple index out of range (reference behaviour: Cxy_Cxy2 on the 1-D means of the "
-                             "[frequency, segment] spectra, fft_analysis.py:1669)")
+                             "[frequency, segment] spectra, fft_analysis.py:1669)")      # (not reached with numpy's size())
         self.pwelch()
+
+    def scipy_stft(self, sig=None):
+        """(freq, t, Zxx[nfreq, nseg]) of scipy.signal.stft as the reference's useMLAB branch calls it (fft_analysis.py:
+        1814-1822), frames on the GPU -- the part of `stft()` with useMLAB=True that works; `stft()` itself ends in the
+        reference's exception.  sig: default self.sigx."""
+        return self._scipy_stft(self.sigx if sig is None else sig)
 
     def fftpwelch(self):
         self.freq, self.Pxy, self.Pxx, self.Pyy, self.Cxy, self.phi_xy, self.fftinfo = fft_pwelch(

@@ -233,3 +233,62 @@ def test_device_tensor_argument_validation(P):
         P.fft_analysis.psd(np.zeros(4096, dtype=np.complex128), 1.0)     # was: imaginary part silently dropped
     pxx, pyy, pxy = E.welch_csd(x + 1, (x + 2)[None, :], w, 128, 4, detrend=False)
     assert pxx.is_cuda and pyy.shape == (1, 128)
+
+
+def test_unstable_biquad_is_refused():
+    """the blocked scan raises the state map to powers up to n -- an unstable section (|p| > 1) would overflow them
+    and NaN every output, where scipy.signal.lfilter returns valid early samples; both layers refuse with a clear error"""
+    from pyfft_amd import engine as E
+    from pyfft_amd import _ffi
+    x = np.ones(4096, dtype=np.float32)
+    with pytest.raises(ValueError, match="unstable"):
+        E.biquad_filter([1.0, 0.0, 0.0], [1.0, -2.1, 1.1025], x)            # double pole at 1.05
+    b = np.array([1.0, 0.0, 0.0]); a = np.array([1.0, -2.1, 1.1025]); y = np.empty_like(x)
+    rc = _ffi.lib().sp_biquad(_ffi.ptr(b), _ffi.ptr(a), _ffi.ptr(x), x.size, _ffi.ptr(y), 0)
+    assert rc != 0 and b"unstable" in _ffi.lib().sp_last_error()
+    # marginally stable (|p| = 1: an integrator) and a stable resonator still run
+    yi = E.biquad_filter([1.0, 0.0, 0.0], [1.0, -1.0, 0.0], x)
+    np.testing.assert_allclose(yi, np.arange(1, 4097, dtype=np.float64), rtol=1e-6)
+    ys = E.biquad_filter([1.0, 0.0, 0.0], [1.0, -1.8, 0.9], x)
+    assert np.all(np.isfinite(ys))
+
+
+def test_sharded_psd_refuses_long_segments_cleanly():
+    """the sharded / split Welch entry points have no long-segment path (nfft > 8192: few, large frames --
+    nothing to shard); they must say so instead of failing somewhere inside (from dist.welch_psd_sharded too)"""
+    from pyfft_amd import engine as E
+    from pyfft_amd._ffi import SpectralError
+    from pyfft_amd.dist import shard_plan, welch_psd_sharded
+    nfft, hop = 16384, 8192
+    x = (np.random.default_rng(0).standard_normal(nfft * 5)).astype(np.float32)
+    win = np.hanning(nfft)
+    plan = shard_plan(x.size, nfft, hop, 1, 0)
+    for fn in (lambda: welch_psd_sharded(x, win, plan, 1.0),
+               lambda: E.welch_export(x, win, hop, plan.frames),
+               lambda: E.welch_accum(x, win, hop, plan.frames),
+               lambda: E.welch_apply(np.zeros(5 * nfft + 8), win, plan.frames)):
+        with pytest.raises(SpectralError, match="not sharded"):
+            fn()
+    # the one-GPU call takes the long-segment path
+    p = E.welch_psd(x, win, hop, plan.frames, detrend=True, sided=E.SIDED_ONE, scale=1.0)
+    assert p.shape == (nfft // 2,) and np.all(np.isfinite(p))
+
+
+def test_csd_epilogue_is_scale_invariant():
+    """the epilogue's inverse transforms run in float32 -- rows are normalised first, so spectra of a 1e-10-volt
+    signal (P ~ 1e-26: float32 denormals when cast as they stand) or of a 1e+12 one give the O(1) case's correlations times
+    the scale, and the same (scale-free) corrcoef"""
+    from pyfft_amd import engine as E
+    rng = np.random.default_rng(2)
+    nfft, nb, nch = 512, 256, 3
+    pxx = rng.random(nb) + 0.1
+    pyy = rng.random((nch, nb)) + 0.1
+    pxy = (rng.standard_normal((nch, nb)) + 1j * rng.standard_normal((nch, nb))) * 0.2
+    base = E.csd_epilogue(pxx, pyy, pxy, nfft, True, 1.5)
+    for sc in (1e-26, 1e+24):
+        r = E.csd_epilogue(pxx * sc, pyy * sc, pxy * sc, nfft, True, 1.5)
+        for k in ("Rxx", "Ryy", "Rxy"):
+            assert np.all(np.isfinite(r[k]))
+            np.testing.assert_allclose(np.asarray(r[k]) / sc, base[k], rtol=1e-5, atol=1e-6 * np.abs(base[k]).max(), err_msg=k)
+        np.testing.assert_allclose(r["corrcoef"], base["corrcoef"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r["Cxy2"], base["Cxy2"], rtol=1e-9)

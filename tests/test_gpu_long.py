@@ -338,3 +338,38 @@ def test_long_paths_on_device_tensors(P):
     s_h, _ = E.stft_frames(x, win, hop, M, detrend=True, sided=E.SIDED_ONE, amp_scale=1.0)
     assert s_t.is_cuda and s_t.shape == (M, nfft // 2)
     np.testing.assert_allclose(s_t.cpu().numpy(), s_h, rtol=0, atol=0)
+
+
+# ---- N2: the multi-channel driver (HeatPulse_Funcs._PWELCH_chloop) as ONE call -----------------------------------------
+@pytest.mark.parametrize("Navr", [8, 64])
+def test_pwelch_chloop_golden(P, Navr):
+    """pyfft_amd.pwelch_chloop: reference signal x 16 channels in one fft_pwelch call on the GPU (reference transformed once),
+    then integratespectra per harmonic band, all channels at once -- against the fixture that loops the reference's OWN
+    fft_pwelch + integratespectra per channel (make_golden_chloop.py; HeatPulse_Funcs.py:576-583, :498-530).  Navr = 8 is the
+    reference's default regime (7281-point segments: the long-segment path), Navr = 64 one fused kernel (1008 points,
+    Bluestein).  trapz_var / reshapech: stand-ins, PARITY UNPINNED at that boundary (recorded in the generator)."""
+    import inputs_chloop
+    g = load_golden("chloop")
+    tag = "n%d" % Navr
+    tt, ref, sig = inputs_chloop.chloop_inputs(int(g["seed"]), int(g["nt"]), float(g["fs"]), int(g["nch"]), float(g["fmod"]))
+    hp = P.pwelch_chloop(tt, ref, sig, float(g["fmod"]), harms=list(g["harms"]), fwid=float(g["fwid"]), Navr=Navr,
+                         windowoverlap=0.5, windowfunction="hanning")
+    assert hp.fftinfo.nwins == int(g["nwins_" + tag]) and hp.Navr == int(g["Navr_" + tag])
+    np.testing.assert_allclose(hp.freq, g["freq_" + tag], rtol=1e-12, atol=1e-12)
+    assert list(hp._ifk) == list(g["ifk_" + tag]) and hp._ifw == int(g["ifw_" + tag])
+    sub = int(g["sub_" + tag])
+    close_rel(hp.Pxx, g["Pxx_" + tag], 2e-4, "Pxx")
+    close_rel(hp.Pyy[::sub], g["Pyy_" + tag], 2e-4, "Pyy")
+    close_rel(hp.Pxy[::sub], g["Pxy_" + tag], 2e-4, "Pxy")
+    # band integrals: float32 spectra integrated over a few bins around a strong line
+    for k in ("Txy", "Amp", "Txx", "Tnn"):
+        ref_k = g[k + "_" + tag]
+        assert np.max(np.abs(getattr(hp, k) - ref_k) / np.abs(ref_k)) <= 5e-4, k
+    for k in ("Vxy", "varA", "Vxx"):
+        ref_k = g[k + "_" + tag]
+        assert np.max(np.abs(getattr(hp, k) - ref_k)) <= 2e-3 * np.max(np.abs(ref_k)), k
+    np.testing.assert_allclose(hp.Coh, g["Coh_" + tag], rtol=0, atol=2e-4)
+    np.testing.assert_allclose(hp.varC, g["varC_" + tag], rtol=2e-2, atol=1e-7)
+    np.testing.assert_allclose(hp.varP, g["varP_" + tag], rtol=2e-2, atol=1e-7)
+    dphi = np.angle(np.exp(1j * (hp.Phase - g["Phase_" + tag])))
+    assert np.max(np.abs(dphi)) <= 1e-3

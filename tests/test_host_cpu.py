@@ -163,10 +163,15 @@ def test_table_cache_policy(tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "cache_policy_test")
-    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "pyfft_amd", "csrc"),
+    # with AddressSanitizer + UndefinedBehaviorSanitizer on the CPU build (sanitizers; GPU ASan is not
+    # available on this pool): any out-of-bounds / use-after-free / UB in the policy code fails the run
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-fno-omit-frame-pointer", "-I" + os.path.join(root, "pyfft_amd", "csrc"),
                     os.path.join(root, "tests", "cache_policy_test.cpp"), "-o", exe], check=True)
-    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    assert "cache policy ok" in out
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cache policy ok" in r.stdout
+    assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
 
 
 def test_uncertainty_and_band_integration_match_reference():
@@ -199,3 +204,12 @@ def test_uncertainty_and_band_integration_match_reference():
     # defaults: the reference's own default branch cannot run (numpy.size_like does not exist); zeros are used
     r = pyfft_amd.integratespectra(freq, Pxy[:, 0], Pxx, Pyy[:, 0], list(g["frange"]))
     np.testing.assert_allclose(np.asarray(r[0]).ravel()[0], g["Pxy_i"].ravel()[0], rtol=1e-12)
+
+
+def test_heatpulse_harmonic_search_matches_reference_bookkeeping():
+    """pyfft_amd.heatpulse.harmonic_indices (HeatPulse_Funcs.py:412-441) on the reference's own averaged Pxx (chloop.npz)"""
+    from pyfft_amd.heatpulse import harmonic_indices
+    g = load_golden("chloop")
+    for tag in ("n8", "n64"):
+        ifk, ifw = harmonic_indices(g["freq_" + tag], g["Pxx_" + tag], float(g["fmod"]), list(g["harms"]), float(g["fwid"]))
+        assert list(ifk) == list(g["ifk_" + tag]) and ifw == int(g["ifw_" + tag])
