@@ -235,8 +235,12 @@ def main():
     collective = world > 1 or force_dist
     # the library's own RCCL communicator (one ctypes call per step, no host work between the kernels and the collective)
     native = collective and not one_gpu and os.environ.get("SP_BENCH_NATIVE_COMM", "1") not in ("", "0")
+    native_note = None
     if native:
-        native_comm_init(device=local)
+        try:
+            native_comm_init(device=local)
+        except Exception as exc:          # (collective: every rank sees the same failure) -> torch.distributed carries the state
+            native, native_note = False, "native RCCL communicator unavailable (%r): torch.distributed path" % (exc,)
 
     nfft = args.nfft
     hop = nfft // 2
@@ -300,6 +304,7 @@ def main():
                                   "issued through torch.distributed (WelchPipeline)")
                                   if collective else "single GPU, no collective"},
         "host_enqueue_ms_per_step": 1e3 * m["enqueue"] / args.steps,
+        **({"note": native_note} if native_note else {}),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": pmc_traffic(args.log2n, nfft) if (world == 1 and not force_dist) else None,

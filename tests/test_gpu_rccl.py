@@ -51,3 +51,15 @@ def test_bench_force_dist_world1():
     d2 = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--settle-steps", "2",
                "--log2n", "24"], {"SP_BENCH_FORCE_DIST": "1", "SP_BENCH_NATIVE_COMM": "0"})
     assert d2["value"] > 0 and "error" not in d2 and "torch.distributed" in d2["config"]["parallelism"]
+
+
+def test_bench_two_ranks_one_gpu_strong_and_weak():
+    """bench.py --gpus 2 on the one GPU of the box (SP_BENCH_ONE_GPU=1: both ranks on cuda:0, gloo carries the state -- RCCL
+    refuses two ranks per device): the strong-scaling split of ONE stream is the headline, the weak figure an extra key, and
+    both parity gates (prefix against the CPU oracle, sharded against one GPU's PSD of the whole stream) hold at N = 2"""
+    d = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--settle-steps", "1",
+              "--log2n", "23", "--gate-log2n", "20"], {"SP_BENCH_ONE_GPU": "1"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and "error" not in d
+    assert d["config"]["total_samples"] == 1 << 23 and d["config"]["samples_per_gpu"] <= (1 << 22) + 4096
+    assert d["parity"]["prefix_vs_oracle"]["ok"] and d["parity"]["sharded_vs_single_gpu"]["ok"]
+    assert d["weak_scaling"]["samples_per_gpu"] >= 1 << 23 and d["weak_scaling"]["value"] > 0
