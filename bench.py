@@ -95,9 +95,10 @@ def self_launch(ngpus):
 def measure(E, x, plan, win, scale, world, dist, dev, args, collective, native):
     """settle + warm-up + EXACTLY args.steps timed steps of the hot path over this rank's shard `x` (barrier + synchronize on
     both sides, max over ranks), then the dominant kernel's duration by HIP events in further untimed steps."""
-    if not collective:
-        pipe = None
-    elif native:           # the whole step inside libspectral: export -> ncclAllReduce (its own stream) -> apply, one call
+    if not collective and not native:
+        pipe = None        # plain calls: E.welch_psd per step (SP_BENCH_STREAM=0)
+    elif native:           # the streaming engine of libspectral (sp_welch_dist_submit): one call per step; the epilogue -- and at
+        #                    N > 1 the ncclAllReduce of the shard state -- run on the library's stream beside the next main kernel
         pipe = NativeWelchPipeline(win, plan, scale=scale, sided=E.SIDED_TWO)
     else:                  # torch.distributed carries the state (gloo rehearsals; SP_BENCH_NATIVE_COMM=0)
         pipe = WelchPipeline(win, plan, scale=scale, sided=E.SIDED_TWO, force_collective=collective)
@@ -241,6 +242,10 @@ def main():
             native_comm_init(device=local)
         except Exception as exc:          # (collective: every rank sees the same failure) -> torch.distributed carries the state
             native, native_note = False, "native RCCL communicator unavailable (%r): torch.distributed path" % (exc,)
+    has_comm = native
+    # one GPU, no collective: the same streaming engine without a communicator (SP_BENCH_STREAM=0: plain sp_welch_psd calls)
+    if not collective and os.environ.get("SP_BENCH_STREAM", "1") not in ("", "0"):
+        native = True
 
     nfft = args.nfft
     hop = nfft // 2
@@ -302,7 +307,9 @@ def main():
                                   "overlapped with the next step's kernels; %s" % (world, 5 * nfft + 8,
                                   "issued by libspectral on its own stream (sp_welch_dist_submit)" if native else
                                   "issued through torch.distributed (WelchPipeline)")
-                                  if collective else "single GPU, no collective"},
+                                  if collective else ("single GPU, no collective; steps streamed through sp_welch_dist_submit (the "
+                                  "epilogue of step k runs beside the main kernel of step k+1; K submits + the flush are inside "
+                                  "the timed region)" if native else "single GPU, no collective; one sp_welch_psd call per step")},
         "host_enqueue_ms_per_step": 1e3 * m["enqueue"] / args.steps,
         **({"note": native_note} if native_note else {}),
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -369,6 +376,8 @@ def main():
         tc = time.perf_counter() - t1
         got = E.welch_psd(x[:nc], win, hop, Mc, detrend=True, sided=E.SIDED_TWO, scale=scale).cpu().numpy()
         err = tol_ratio(got, ref)
+        if nc == S:           # the timed loop's own last result (streamed steps) against the same oracle
+            err = max(err, tol_ratio(m["pxx"].cpu().numpy(), ref))
         one = {"value": (nc / 1e6) / tc, "unit": "Msamples/s", "cores": 1, "seconds": tc}
         cores = cpu_parallel.usable_cores(args.cpu_cores)
         result["cpu_baseline"] = dict(one, kind="port",
@@ -396,7 +405,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if native:
+    if has_comm:
         torch.cuda.synchronize()
         E.comm_destroy()
     if dist is not None:

@@ -115,31 +115,34 @@ int sp_welch_export(const void *x, int x_dtype, int64_t nsig, const float *win, 
 int sp_welch_apply(const double *state, const float *win, int nfft, int64_t frames_total, int sided, double scale,
                    double *pxx_out, int mem);
 
-/* ---- the same path across the GPUs of one node WITHOUT the host in the loop (SURVEY section 8b sketched `sp_init(device_count,
- *      device_ids)` + an `ngpu` argument; the MI355X-native form is one process per GPU with the library owning an RCCL
- *      communicator).  Every process: sp_init(its device); rank 0 calls sp_comm_unique_id and hands the SP_COMM_ID_BYTES to
- *      the others by any means (the Python layer: one torch.distributed broadcast; a C host: MPI / a file / a socket); all
- *      call sp_comm_init(id, world, rank) (collective).  RCCL is resolved at run time (dlopen "librccl.so.1": the copy
- *      already in the process if there is one), so the library loads without it.
- *      sp_welch_dist_submit = sp_welch_export of this shard's frames + ONE ncclAllReduce (sum, double, 5 nfft + 8 values)
- *      on the library's collective stream, ordered behind the export by an event -- and then the sp_welch_apply of the
- *      PREVIOUS submit, whose all-reduce has had this step's kernels to finish: pxx_prev[nbins] receives the PSD of the whole
- *      stream of the previous step when *have_prev = 1 (nothing pending: 0, pxx_prev untouched).  sp_welch_dist_flush
- *      finishes the last submit.  K submits + one flush = K Welch PSDs of the sharded stream; no host synchronisation with
- *      mem = 1.  frames_total = frames of the WHOLE stream (the normalisation); nmean = this shard's own samples (halo
- *      excluded).  sp_welch_psd_dist = submit + flush (no overlap).  Reference path: the same as sp_welch_psd
- *      (fft_analysis.py:2126-2203, :1944-1990) over segments dealt out to the ranks. */
+/* ---- the same path as a STREAM of steps, on one GPU or across the GPUs of one node, without the host in the loop (device
+ *      pointers only).  SURVEY section 8b sketched `sp_init(device_count, device_ids)` + an `ngpu` argument; the MI355X-native
+ *      form is one process per GPU with the library owning an RCCL communicator.
+ *      Communicator (optional): every process sp_init(its device); rank 0 calls sp_comm_unique_id and hands the
+ *      SP_COMM_ID_BYTES to the others by any means (the Python layer: one torch.distributed broadcast; a C host: MPI / a file /
+ *      a socket); all call sp_comm_init(id, world, rank) (collective).  RCCL is resolved at run time (dlopen "librccl.so.1":
+ *      the copy already in the process if there is one), so the library loads without it.
+ *      sp_welch_dist_submit(step k): this shard's main kernel on the launch stream; its epilogue on the library's own stream
+ *      behind an event -- without communicator the finished PSD, with one the shard's additive state (sp_welch_export), ONE
+ *      ncclAllReduce (sum, double, 5 nfft + 8 values) and the sp_welch_apply, folded into the next step's epilogue launch --
+ *      so the epilogue and the collective run BESIDE the next step's main kernel.  pxx_out[nbins] (device) receives THIS
+ *      step's PSD of the whole stream; it is valid on the launch stream once a later call has reported it: *ndone = how many
+ *      earlier submits' outputs became valid with this call, in submit order (without communicator: step k-1 at submit k;
+ *      with: step k-2).  sp_welch_dist_flush reports the rest.  x, win contents and pxx_out of a step must stay alive until
+ *      it is reported.  K submits + one flush = K Welch PSDs; no host synchronisation.  frames_total = frames of the WHOLE
+ *      stream (the normalisation); nmean = this shard's own samples (halo excluded).  sp_welch_psd_dist = submit + flush.
+ *      Shapes: as sp_welch_export.  Reference path: the same as sp_welch_psd (fft_analysis.py:2126-2203, :1944-1990) over
+ *      segments dealt out to the ranks. */
 #define SP_COMM_ID_BYTES 128
 int sp_comm_unique_id(void *id_out /* SP_COMM_ID_BYTES */);
 int sp_comm_init(const void *id, int world, int rank);
 int sp_comm_info(int out[2] /* world (0 = no communicator), rank */);
 int sp_comm_destroy(void);
 int sp_welch_dist_submit(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-                         int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_prev, int *have_prev,
-                         int mem);
-int sp_welch_dist_flush(double *pxx_out, int *have, int mem);
+                         int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_out, int *ndone);
+int sp_welch_dist_flush(int *ndone);
 int sp_welch_psd_dist(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-                      int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_out, int mem);
+                      int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_out);
 
 /* ---- A5: fft_pwelch numeric core (fft_analysis.py:339-446): reference x against nch
  *      channels y[c][0:nsig] (channel-major, row stride y_ld samples).

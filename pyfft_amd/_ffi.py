@@ -43,9 +43,9 @@ SIGNATURES = {
     "sp_comm_init": (_i, [_vp, _i, _i]),
     "sp_comm_info": (_i, [C.POINTER(_i)]),
     "sp_comm_destroy": (_i, []),
-    "sp_welch_dist_submit": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i64, _i64, _i, _d, _vp, C.POINTER(_i), _i]),
-    "sp_welch_dist_flush": (_i, [_vp, C.POINTER(_i), _i]),
-    "sp_welch_psd_dist": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i64, _i64, _i, _d, _vp, _i]),
+    "sp_welch_dist_submit": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i64, _i64, _i, _d, _vp, C.POINTER(_i)]),
+    "sp_welch_dist_flush": (_i, [C.POINTER(_i)]),
+    "sp_welch_psd_dist": (_i, [_vp, _i, _i64, _vp, _i, _i, _i64, _i64, _i64, _i, _d, _vp]),
     "sp_welch_csd": (_i, [_vp, _vp, _i, _i64, _i, _i64, _vp, _i, _i, _i64, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _i]),
     "sp_csd_matrix": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i, _i64, _i, _d, _vp, _i]),
     "sp_csd_matrix_means": (_i, [_vp, _i, _i64, _i64, _vp, _i, _i, _i64, _vp, _d, _vp, _i]),

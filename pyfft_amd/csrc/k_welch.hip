@@ -212,18 +212,23 @@ int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, 
 
 int launch_op_fused(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, const float *partial,
                     const cf *spartial, int64_t G, int n, int hop, int64_t nframes, int64_t nmean, OnePass st, unsigned *ticket,
-                    CogLobe lb, const double *mean_in, int sided, double scale, double *out, bool export_state, OpPrev prev) {
+                    CogLobe lb, const double *mean_in, int sided, double scale, double *out, bool export_state, OpPrev prev, bool light) {
     if (n % hop != 0 || n / hop > 4 || (hop & (hop - 1)) != 0 || n % 32 != 0 || (2 * hop) % 32 != 0 || lb.K < 0 || lb.K > 3 || n < 2 * lb.K + 2)
         return -1;
-    const dim3 grid(n / 32 + (2 * hop) / 32), block(SP_OPF_WG);
-    const double ang = -2.0 * M_PI * (double)SP_OPF_WG / (double)n;            // the bin-to-bin rotation of the last block's twiddles
+    const int wg = light ? SP_OPF_WG_LIGHT : SP_OPF_WG;
+    const dim3 grid(n / 32 + (2 * hop) / 32), block(wg);
+    const double ang = -2.0 * M_PI * (double)wg / (double)n;                   // the bin-to-bin rotation of the last block's twiddles
     const double step_c = cos(ang), step_s = sin(ang);
-#define FUSED_(CP, EX, EE)                                                                             \
-    hipLaunchKernelGGL((k_op_fused<CP, EX, EE>), grid, block, 0, c.stream, partial, n, st.A, reinterpret_cast<const float *>(spartial), \
+#define FUSED_(CP, EX, EE, LT)                                                                         \
+    hipLaunchKernelGGL((k_op_fused<CP, EX, EE, LT>), grid, block, 0, c.stream, partial, n, st.A, reinterpret_cast<const float *>(spartial), \
                        hop, st.Sl, G, ticket, x, trend, win, lb, mean_in, nframes, nmean, sided, scale, out, st.sym, prev, step_c, step_s)
 #define FUSED_E_(CP, EX)                                                                               \
     {                                                                                                 \
-        if (n / hop <= 2) FUSED_(CP, EX, 1); else FUSED_(CP, EX, 3);                                   \
+        if (light) {                                                                                  \
+            if (n / hop <= 2) FUSED_(CP, EX, 1, true); else FUSED_(CP, EX, 3, true);                   \
+        } else {                                                                                      \
+            if (n / hop <= 2) FUSED_(CP, EX, 1, false); else FUSED_(CP, EX, 3, false);                 \
+        }                                                                                             \
     }
     if (cplx) {
         if (export_state) FUSED_E_(true, true) else FUSED_E_(true, false)

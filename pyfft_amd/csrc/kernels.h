@@ -2042,9 +2042,16 @@ struct OpPrev {                 // the previous step of the pipelined sharded PS
 };
 // E = edge blocks of c[n] per side: 1 for hop = N/2 and hop = N, 3 for hop = N/4.  512 threads (256 VGPRs: the last block keeps
 // eight bins per thread in flight; at 1024 threads / 128 VGPRs the same code spilled 450 registers and ran 5x slower).
+// LIGHT: the form the streaming engine launches on its own stream so that it runs BESIDE the next step's main kernel: that kernel
+// (k_welch_pipe: 3 waves of 136 VGPRs per SIMD, 128.5 of 160 KiB LDS) leaves 104 VGPRs per SIMD and plenty of wave slots, so a
+// workgroup of 256 threads (one wave per SIMD) with <= 104 VGPRs fits next to it (the 512-thread form with 190 does not: its
+// workgroups waited for the main kernel to drain and the overlap was lost, profiles/r03_stream_overlap.txt).  Two bins per thread
+// and chunk: more round trips for the last block, which nobody waits for.
 #define SP_OPF_WG 512
-template <bool CPLX, bool EXPORT, int E>
-static __global__ __launch_bounds__(SP_OPF_WG) void k_op_fused(const float *__restrict__ m0, int N, double *__restrict__ Acol,
+#define SP_OPF_WG_LIGHT 256
+template <bool CPLX, bool EXPORT, int E, bool LIGHT = false>
+static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
+    __attribute__((amdgpu_waves_per_eu(LIGHT ? 5 : 2, LIGHT ? 8 : 2))) void k_op_fused(const float *__restrict__ m0, int N, double *__restrict__ Acol,
                                                                 const float *__restrict__ m1, int H, double *__restrict__ Sl,
                                                                 int64_t G, unsigned *__restrict__ ticket,
                                                                 const void *__restrict__ x, const float *__restrict__ trend,
@@ -2052,7 +2059,7 @@ static __global__ __launch_bounds__(SP_OPF_WG) void k_op_fused(const float *__re
                                                                 const double *__restrict__ mean_in, int64_t M, int64_t nmean,
                                                                 int sided, double scale, double *__restrict__ out, int sym,
                                                                 OpPrev prev, double step_c, double step_s) {
-    constexpr int WG = SP_OPF_WG, NW = WG / 64, NSL = WG / 8;
+    constexpr int WG = LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG, NW = WG / 64, NSL = WG / 8;
     OPF_STAMP(ts_start);
     __shared__ double sh[NW][32];
     __shared__ double tot_sh[16];
@@ -2156,7 +2163,7 @@ static __global__ __launch_bounds__(SP_OPF_WG) void k_op_fused(const float *__re
             acc[1] += sgn * v.y;
         }
     }
-    constexpr int NPT = (E > 1 && CPLX) ? 4 : 8;    // bins per thread and chunk: N <= 4096 is one chunk, one round trip (hop = N/4, complex: two)
+    constexpr int NPT = LIGHT ? 2 : ((E > 1 && CPLX) ? 4 : 8);    // bins per thread and chunk: N <= 4096 is one chunk, one round trip (hop = N/4, complex: two)
     double ak[NPT];                                 // raw sums A[k] of the thread's bins (kept for the output loop)
     // uniform bases + 32-bit lane offsets (scalar-base addressing: one offset register per load instead of a 64-bit address)
     const char *xh = reinterpret_cast<const char *>(x), *xt = xh + M * (int64_t)H * (CPLX ? 8 : 4);

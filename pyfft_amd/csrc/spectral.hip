@@ -690,18 +690,27 @@ struct FusedOut {
     hipEvent_t prev_wait = nullptr;
     bool prev_done = false;
 };
-unsigned *get_ticket() {
-    if (!g.ticket.p) {                  // 9 counters, 64 bytes apart (k_op_fused)
-        if (g.ticket.ensure(1024)) return nullptr;
-        if (hipMemset(g.ticket.p, 0, 1024) != hipSuccess) return nullptr;
+unsigned *get_ticket(Scratch &t) {
+    if (!t.p) {                         // 9 counters, 64 bytes apart (k_op_fused)
+        if (t.ensure(1024)) return nullptr;
+        if (hipMemset(t.p, 0, 1024) != hipSuccess) return nullptr;
     }
-    return (unsigned *)g.ticket.p;
+    return (unsigned *)t.p;
 }
+// streaming engine (sp_welch_dist_*): a scratch set of its own per step parity, and the epilogue launched on another stream
+// behind an event recorded after the main kernel -- so that it runs beside the NEXT step's main kernel
+struct SplitLaunch {
+    Scratch *work, *onepass, *trend, *ticket;
+    hipStream_t epi;
+    hipEvent_t ev_main;
+};
 
 // want_sum: also produce the shard's plain sample sum (split ABI, one more tiny launch); without it the finish kernel
 // derives the shard mean itself
 int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-                       int64_t nmean, bool want_sum, FusedOut *fo = nullptr) {
+                       int64_t nmean, bool want_sum, FusedOut *fo = nullptr, const SplitLaunch *sl = nullptr) {
+    Scratch &S_work = sl ? *sl->work : g.work, &S_one = sl ? *sl->onepass : g.onepass, &S_trend = sl ? *sl->trend : g.pend_trend;
+    Scratch &S_ticket = sl ? *sl->ticket : g.ticket;
     if (!wg_capable(nfft))
         return fail("sharded / split Welch PSD (sp_welch_accum, sp_welch_export, sp_welch_dist_*): segments longer than one workgroup "
                     "transform are not sharded (nfft = %d; powers of two in [256, %d] with hop = nfft/4, nfft/2 or nfft) -- the "
@@ -717,8 +726,8 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     void *Wf_d;
     if (get_window_spectrum(win, nfft, xf, &Wf_d)) return -1;
     // its own trend record: calls between sp_welch_accum and sp_welch_finish reuse the shared one
-    if (g.pend_trend.ensure(256)) return -1;
-    TrendBuf tb{(float *)g.pend_trend.p, nullptr};
+    if (S_trend.ensure(256)) return -1;
+    TrendBuf tb{(float *)S_trend.p, nullptr};
     // real input at hop = nfft/2: two frames per transform on the pipeline (k_welch_pipe modes 3/4), partitioned over frame PAIRS
     const bool realpair = !cplx && 2 * hop == nfft && nframes >= 2 && !env_flag("SP_NO_REALPAIR") &&
                           welch_pipe_wanted(xf, hop, (nframes + 1) / 2);
@@ -728,22 +737,22 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     const bool pipe = realpair || ((hop != nfft || welch_pipe_mode() >= 2) && welch_pipe_wanted(xf, hop, nframes));
     const RunPart rp = realpair ? run_partition(xf.L, (nframes + 1) / 2, g.ncu, welch_pipe_gpc())
                                 : (pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc()) : run_partition(xf.L, nframes, g.ncu));
-    if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
+    if (S_work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
     const size_t sp_bytes = sizeof(cf) * (size_t)rp.groups * (size_t)hop;
     const size_t st_doubles = (size_t)nfft + 2 * (size_t)hop + 8;
     const size_t sp_pad = (sp_bytes + 255) & ~(size_t)255;
     const size_t st_pad = (sizeof(double) * st_doubles + 255) & ~(size_t)255;
-    if (g.onepass.ensure(sp_pad + st_pad + sizeof(cf) * (size_t)nfft)) return -1;
-    cf *spartial = (cf *)g.onepass.p;
-    double *stp = (double *)((char *)g.onepass.p + sp_pad);
+    if (S_one.ensure(sp_pad + st_pad + sizeof(cf) * (size_t)nfft)) return -1;
+    cf *spartial = (cf *)S_one.p;
+    double *stp = (double *)((char *)S_one.p + sp_pad);
     OnePass st;
     st.A = stp;
     st.Sl = stp + nfft;
     st.tot = st.Sl + 2 * (size_t)hop;
     st.dlt = st.tot + 2;
     double *sum_d = st.dlt + 2;
-    cf *cw = (cf *)((char *)g.onepass.p + sp_pad + st_pad);
-    float *partial = (float *)g.work.p;
+    cf *cw = (cf *)((char *)S_one.p + sp_pad + st_pad);
+    float *partial = (float *)S_work.p;
     double *est = moments_scratch();
     if (!est) return -1;
 #if !SP_EST_IN_KERNEL
@@ -763,19 +772,27 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
                                spartial, &g.last_kernel));
     }
     if (!want_sum) st.dlt = nullptr;
+    // the epilogue's launch context: the launch stream, or the engine's epilogue stream behind the main kernel's event
+    LaunchCtx ec = lc();
+    if (sl) {
+        HIPCHK(hipEventRecord(sl->ev_main, g.stream));
+        HIPCHK(hipStreamWaitEvent(sl->epi, sl->ev_main, 0));
+        ec = LaunchCtx{sl->epi, g.ncu};
+    }
     CogLobe lobe{};
     if (fo && !want_sum && !env_flag("SP_OP_UNFUSED") && cog_window_lobe(win, nfft, &lobe)) {
-        unsigned *ticket = get_ticket();
+        unsigned *ticket = get_ticket(S_ticket);
         if (!ticket) return fail("ticket allocation failed");
-        if (fo->prev.st && fo->prev_wait) HIPCHK(hipStreamWaitEvent(g.stream, fo->prev_wait, 0));
-        LAUNCHCHK(launch_op_fused(lc(), xd, cplx, tb.f, (const float *)win_d, partial, spartial, rp.groups, nfft, hop, nframes, nmean,
-                                  st, ticket, lobe, nullptr, fo->sided, fo->scale, fo->out, fo->export_state, fo->prev));
+        if (fo->prev.st && fo->prev_wait) HIPCHK(hipStreamWaitEvent(ec.stream, fo->prev_wait, 0));
+        LAUNCHCHK(launch_op_fused(ec, xd, cplx, tb.f, (const float *)win_d, partial, spartial, rp.groups, nfft, hop, nframes, nmean,
+                                  st, ticket, lobe, nullptr, fo->sided, fo->scale, fo->out, fo->export_state, fo->prev,
+                                  sl != nullptr && !env_flag("SP_OPF_HEAVY")));
         fo->done = true;
         fo->prev_done = fo->prev.st != nullptr;
         g_pend.valid = false;
         return 0;
     }
-    LAUNCHCHK(launch_op_reduce(lc(), xd, cplx, tb.f, partial, spartial, rp.groups, xf, hop, nframes, nmean, st,
+    LAUNCHCHK(launch_op_reduce(ec, xd, cplx, tb.f, partial, spartial, rp.groups, xf, hop, nframes, nmean, st,
                                want_sum ? sum_d : nullptr));
     g_pend.valid = true;
     g_pend.xd = xd;
@@ -796,10 +813,10 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
 }
 
 int welch_finish_locked(const double *mean_d /*device or null*/, int64_t frames_total, int sided, double scale,
-                        double *out_d) {
+                        double *out_d, const LaunchCtx *ctx = nullptr) {
     if (!g_pend.valid) return fail("sp_welch_finish: no pending sp_welch_accum");
     g_pend.valid = false;
-    LAUNCHCHK(launch_op_finish(lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, mean_d, g_pend.nmean,
+    LAUNCHCHK(launch_op_finish(ctx ? *ctx : lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, mean_d, g_pend.nmean,
                                g_pend.xf, g_pend.hop, g_pend.nframes, g_pend.cw, g_pend.Wf, sided,
                                scale / (double)frames_total, out_d));
     return 0;
@@ -840,53 +857,91 @@ int rccl_load() {
         if (r_ != ncclSuccess) return fail("%s failed: %s (%s:%d)", #expr, rccl.GetErrorString(r_), __FILE__, __LINE__); \
     } while (0)
 
-// one step of the pipelined sharded PSD waiting for its all-reduce
-struct DistSlot {
-    bool valid = false;
+struct Comm {
+    ncclComm_t comm = nullptr;
+    int world = 0, rank = -1;
+} gcomm;
+
+// ---- the streaming engine behind sp_welch_dist_submit / _flush ------------------------------------------------------------
+// Step k: the main kernel (k_welch_pipe / k_welch_carry) on the launch stream A into the scratch set of parity k & 1; an event;
+// the epilogue on the engine's stream B behind it: k_op_fused (with a communicator: EXPORT of this step's state + the apply of
+// step k-1's all-reduced state, then ncclAllReduce of this step's state, all B-ordered).  A's next main kernel does not depend
+// on B, so the epilogue (15-20 us of mostly one workgroup) and the collective run BESIDE it (tools/ubench/coexec.hip: two
+// kernels from two streams share the CUs when the first leaves registers and wave slots free; the main kernel takes 408 of a
+// SIMD's 512 VGPRs and 12 of a CU's 32 wave slots).  Only then does A wait for the PREVIOUS step's epilogue event -- which is
+// what makes that step's (without communicator) or the step before's (with) output valid for the caller, in stream order.
+struct EngineSlot {
+    bool busy = false;
     std::vector<float> win;
     int64_t frames_total = 0;
     int sided = 0;
     double scale = 0;
+    double *out = nullptr;
 };
-struct Comm {
-    ncclComm_t comm = nullptr;
-    int world = 0, rank = -1;
-    hipStream_t cs = nullptr;                       // the collective's own stream
-    hipEvent_t ev_exp[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
-    Scratch st[2];                                  // the two state buffers in flight
-    DistSlot slot[2];
-    int cur = 0;
-} gcomm;
+struct Engine {
+    hipStream_t epi = nullptr;
+    hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_epi[2] = {nullptr, nullptr};
+    Scratch work[2], onepass[2], trend[2], ticket[2], st[2];
+    EngineSlot slot[2];
+    int64_t nsub = 0;            // submits since the last flush
+    bool with_comm = false;      // mode of the steps in flight
+} geng;
 
-// finish slot s: wait (on the launch stream) for its all-reduce, apply the global mean -> out_d (device)
-int dist_apply_locked(int s, double *out_d) {
-    DistSlot &sl = gcomm.slot[s];
+int engine_init() {
+    if (geng.epi) return 0;
+    HIPCHK(hipStreamCreateWithFlags(&geng.epi, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&geng.ev_main[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&geng.ev_epi[i], hipEventDisableTiming));
+    }
+    return 0;
+}
+void engine_release() {
+    if (!geng.epi) return;
+    (void)hipStreamSynchronize(geng.epi);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipEventDestroy(geng.ev_main[i]);
+        (void)hipEventDestroy(geng.ev_epi[i]);
+        geng.ev_main[i] = geng.ev_epi[i] = nullptr;
+        geng.work[i].release();
+        geng.onepass[i].release();
+        geng.trend[i].release();
+        geng.ticket[i].release();
+        geng.st[i].release();
+        geng.slot[i].busy = false;
+    }
+    (void)hipStreamDestroy(geng.epi);
+    geng.epi = nullptr;
+    geng.nsub = 0;
+}
+
+// apply the all-reduced state of slot s -> its output, on the engine's stream (B-ordered behind the collective)
+int engine_apply_locked(int s) {
+    EngineSlot &sl = geng.slot[s];
     const int nfft = (int)sl.win.size();
     Xf xf;
     if (get_xf(nfft, &xf)) return -1;
     void *Wf_d;
     if (get_window_spectrum(sl.win.data(), nfft, xf, &Wf_d)) return -1;
-    HIPCHK(hipStreamWaitEvent(g.stream, gcomm.ev_red[s], 0));
-    LAUNCHCHK(launch_op_apply(lc(), (const double *)gcomm.st[s].p, (const cf *)Wf_d, nfft, sl.sided, sl.scale / (double)sl.frames_total,
-                              out_d));
-    sl.valid = false;
+    LAUNCHCHK(launch_op_apply(LaunchCtx{geng.epi, g.ncu}, (const double *)geng.st[s].p, (const cf *)Wf_d, nfft, sl.sided,
+                              sl.scale / (double)sl.frames_total, sl.out));
     return 0;
 }
 
 // this shard's additive state (sp_welch_export) into st_d (device, 5 nfft + 8 doubles)
 int welch_export_locked(const void *xd, bool cplx, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
                         int64_t nmean, double *st_d, const OpPrev *prev = nullptr, hipEvent_t prev_wait = nullptr,
-                        bool *prev_done = nullptr) {
+                        bool *prev_done = nullptr, const SplitLaunch *sl = nullptr) {
     FusedOut fo{true, SP_SIDED_RAW, 1.0, st_d, false};
     if (prev) {
         fo.prev = *prev;
         fo.prev_wait = prev_wait;
     }
-    if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, false, &fo)) return -1;
+    if (welch_accum_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, false, &fo, sl)) return -1;
     g_pend.valid = false;
     if (prev_done) *prev_done = fo.prev_done;
     if (fo.done) return 0;
-    LAUNCHCHK(launch_op_finish(lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, nullptr, g_pend.nmean,
+    LAUNCHCHK(launch_op_finish(sl ? LaunchCtx{sl->epi, g.ncu} : lc(), g_pend.xd, g_pend.cplx, g_pend.trend_f, g_pend.win_d, g_pend.st, nullptr, g_pend.nmean,
                                g_pend.xf, g_pend.hop, g_pend.nframes, g_pend.cw, g_pend.Wf, SP_SIDED_RAW, 1.0, st_d, true));
     return 0;
 }
@@ -929,6 +984,7 @@ void sp_shutdown(void) {
     (void)sp_comm_destroy();
     std::lock_guard<std::mutex> lk(g.mu);
     if (!g.ready) return;
+    engine_release();
     (void)hipDeviceSynchronize();
     for (auto &kv : g.twiddles) (void)hipFree(kv.second);
     g.twiddles.clear();
@@ -1300,6 +1356,7 @@ int sp_comm_init(const void *id_in, int world, int rank) {
     if (!id_in || world < 1 || rank < 0 || rank >= world) return fail("sp_comm_init: bad id/world/rank");
     ApiLock lk;
     if (gcomm.comm) return fail("sp_comm_init: a communicator exists already (sp_comm_destroy first)");
+    if (geng.nsub) return fail("sp_comm_init: streaming steps are in flight (sp_welch_dist_flush first)");
     if (rccl_load()) return -1;
     HIPCHK(hipSetDevice(g.device));
     ncclUniqueId id;
@@ -1307,13 +1364,6 @@ int sp_comm_init(const void *id_in, int world, int rank) {
     NCCLCHK(rccl.CommInitRank(&gcomm.comm, world, id, rank));
     gcomm.world = world;
     gcomm.rank = rank;
-    HIPCHK(hipStreamCreateWithFlags(&gcomm.cs, hipStreamNonBlocking));
-    for (int i = 0; i < 2; ++i) {
-        HIPCHK(hipEventCreateWithFlags(&gcomm.ev_exp[i], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&gcomm.ev_red[i], hipEventDisableTiming));
-        gcomm.slot[i].valid = false;
-    }
-    gcomm.cur = 0;
     return 0;
 }
 
@@ -1326,131 +1376,116 @@ int sp_comm_info(int out[2]) {
 int sp_comm_destroy(void) {
     std::lock_guard<std::mutex> lk(g.mu);
     if (!gcomm.comm) return 0;
-    (void)hipStreamSynchronize(gcomm.cs);
+    if (geng.epi) (void)hipStreamSynchronize(geng.epi);
     (void)hipStreamSynchronize(g.stream);
     (void)rccl.CommDestroy(gcomm.comm);
     gcomm.comm = nullptr;
     gcomm.world = 0;
     gcomm.rank = -1;
-    for (int i = 0; i < 2; ++i) {
-        (void)hipEventDestroy(gcomm.ev_exp[i]);
-        (void)hipEventDestroy(gcomm.ev_red[i]);
-        gcomm.ev_exp[i] = gcomm.ev_red[i] = nullptr;
-        gcomm.st[i].release();
-        gcomm.slot[i].valid = false;
-    }
-    (void)hipStreamDestroy(gcomm.cs);
-    gcomm.cs = nullptr;
+    geng.nsub = 0;
+    geng.slot[0].busy = geng.slot[1].busy = false;
     return 0;
 }
 
 int sp_welch_dist_submit(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-                         int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_prev, int *have_prev,
-                         int mem) {
+                         int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_out, int *ndone) {
     if (ensure_init()) return -1;
     if (check_frames("sp_welch_dist_submit", nsig, nfft, hop, nframes)) return -1;
     if (sided < 1 || sided > 3) return fail("sp_welch_dist_submit: bad sided");
     if (frames_total < nframes) return fail("sp_welch_dist_submit: frames_total is the frame count of the WHOLE stream");
-    if (have_prev) *have_prev = 0;
+    if (!x || !pxx_out) return fail("sp_welch_dist_submit: null pointer");
+    if (ndone) *ndone = 0;
     ApiLock lk;
-    if (!gcomm.comm) return fail("sp_welch_dist_submit: no communicator (sp_comm_init)");
+    if (engine_init()) return -1;
+    const bool comm = gcomm.comm != nullptr;
+    if (geng.nsub && comm != geng.with_comm) return fail("sp_welch_dist_submit: communicator changed with steps in flight");
+    geng.with_comm = comm;
     const bool cplx = x_dtype == SP_DTYPE_C64;
-    const size_t esz = cplx ? 8 : 4;
-    const void *xd = x;
-    if (!mem) {
-        if (g.in0.ensure(esz * (size_t)nsig)) return -1;
-        HIPCHK(hipMemcpyAsync(g.in0.p, x, esz * (size_t)nsig, hipMemcpyHostToDevice, g.stream));
-        xd = g.in0.p;
-    }
-    const int s = gcomm.cur, o = 1 - s;
-    if (gcomm.slot[s].valid) return fail("sp_welch_dist_submit: internal slot still busy");
-    const size_t nst = 5 * (size_t)nfft + 8;
-    if (gcomm.st[s].ensure(sizeof(double) * nst)) return -1;
-    double *st_d = (double *)gcomm.st[s].p;
-    // the previous step (its all-reduce has had this step's main kernel to complete): when both steps have the same
-    // transform length, the launch that finishes THIS step's state also applies the previous one (k_op_fused, behind the
-    // collective's event) -- no separate launch
-    DistSlot &po = gcomm.slot[o];
-    const bool have_o = po.valid;
-    double *prev_d = nullptr;
-    int nb_o = 0;
-    OpPrev prev{nullptr, nullptr, nullptr, 0, 0.0};
-    if (have_o) {
-        if (!pxx_prev) return fail("sp_welch_dist_submit: a previous step is pending and pxx_prev is null");
-        nb_o = nbins_host((int)po.win.size(), po.sided);
-        prev_d = pxx_prev;
-        if (!mem) {
-            if (g.out0.ensure(sizeof(double) * (size_t)nb_o)) return -1;
-            prev_d = (double *)g.out0.p;
-        }
-        if ((int)po.win.size() == nfft && !env_flag("SP_DIST_SEPARATE_APPLY")) {
+    const int64_t k = geng.nsub;
+    const int s = (int)(k & 1), o = 1 - s;
+    // slot s held step k - 2: its epilogue event was waited for on the launch stream during submit k - 1 (below), so the main
+    // kernel of this step may overwrite its scratch set
+    EngineSlot &cur = geng.slot[s], &prv = geng.slot[o];
+    SplitLaunch sl{&geng.work[s], &geng.onepass[s], &geng.trend[s], &geng.ticket[s], geng.epi, geng.ev_main[s]};
+    const LaunchCtx ec{geng.epi, g.ncu};
+    if (comm) {
+        const size_t nst = 5 * (size_t)nfft + 8;
+        if (geng.st[s].ensure(sizeof(double) * nst)) return -1;
+        double *st_d = (double *)geng.st[s].p;
+        // the launch that finishes THIS step's state also applies the previous step's all-reduced state (same transform length;
+        // B-ordered behind that step's collective) -- otherwise a k_op_apply launch of its own, on B as well
+        OpPrev prev{nullptr, nullptr, nullptr, 0, 0.0};
+        if (prv.busy && (int)prv.win.size() == nfft && !env_flag("SP_DIST_SEPARATE_APPLY")) {
             Xf xfo;
             if (get_xf(nfft, &xfo)) return -1;
             void *Wf_o;
-            if (get_window_spectrum(po.win.data(), nfft, xfo, &Wf_o)) return -1;
-            prev = OpPrev{(const double *)gcomm.st[o].p, (const cf *)Wf_o, prev_d, po.sided, po.scale / (double)po.frames_total};
+            if (get_window_spectrum(prv.win.data(), nfft, xfo, &Wf_o)) return -1;
+            prev = OpPrev{(const double *)geng.st[o].p, (const cf *)Wf_o, prv.out, prv.sided, prv.scale / (double)prv.frames_total};
         }
+        bool prev_done = false;
+        if (welch_export_locked(x, cplx, nsig, win, nfft, hop, nframes, nmean, st_d, prev.st ? &prev : nullptr, nullptr, &prev_done, &sl))
+            return -1;
+        if (prv.busy && !prev_done && engine_apply_locked(o)) return -1;
+        NCCLCHK(rccl.AllReduce(st_d, st_d, nst, ncclDouble, ncclSum, gcomm.comm, geng.epi));
+    } else {
+        FusedOut fo{false, sided, scale / (double)frames_total, pxx_out, false};
+        if (welch_accum_locked(x, cplx, nsig, win, nfft, hop, nframes, nmean, false, &fo, &sl)) return -1;
+        if (!fo.done && welch_finish_locked(nullptr, frames_total, sided, scale, pxx_out, &ec)) return -1;
     }
-    // this step: the shard's additive state on the launch stream, its all-reduce on the collective's stream behind an event
-    bool prev_done = false;
-    if (welch_export_locked(xd, cplx, nsig, win, nfft, hop, nframes, nmean, st_d, prev.st ? &prev : nullptr, gcomm.ev_red[o], &prev_done))
-        return -1;
-    HIPCHK(hipEventRecord(gcomm.ev_exp[s], g.stream));
-    HIPCHK(hipStreamWaitEvent(gcomm.cs, gcomm.ev_exp[s], 0));
-    NCCLCHK(rccl.AllReduce(st_d, st_d, nst, ncclDouble, ncclSum, gcomm.comm, gcomm.cs));
-    HIPCHK(hipEventRecord(gcomm.ev_red[s], gcomm.cs));
-    gcomm.slot[s].valid = true;
-    gcomm.slot[s].win.assign(win, win + nfft);
-    gcomm.slot[s].frames_total = frames_total;
-    gcomm.slot[s].sided = sided;
-    gcomm.slot[s].scale = scale;
-    gcomm.cur = o;
-    if (have_o) {
-        if (prev_done) po.valid = false;
-        else if (dist_apply_locked(o, prev_d)) return -1;
-        if (!mem) {
-            HIPCHK(hipMemcpyAsync(pxx_prev, prev_d, sizeof(double) * (size_t)nb_o, hipMemcpyDeviceToHost, g.stream));
-            HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipEventRecord(geng.ev_epi[s], geng.epi));
+    cur.busy = true;
+    cur.win.assign(win, win + nfft);
+    cur.frames_total = frames_total;
+    cur.sided = sided;
+    cur.scale = scale;
+    cur.out = pxx_out;
+    geng.nsub = k + 1;
+    // the previous step's epilogue has had this step's main kernel to run beside: wait for it on the launch stream NOW (behind
+    // the main kernel just enqueued).  That makes valid, in stream order: without communicator the output of step k - 1; with
+    // one the output of step k - 2 (applied by step k - 1's epilogue launch).
+    if (prv.busy) {
+        HIPCHK(hipStreamWaitEvent(g.stream, geng.ev_epi[o], 0));
+        if (!comm) {
+            prv.busy = false;
+            if (ndone) *ndone = 1;
+        } else if (k >= 2 && ndone) {
+            *ndone = 1;
         }
-        if (have_prev) *have_prev = 1;
     }
     return 0;
 }
 
-int sp_welch_dist_flush(double *pxx_out, int *have, int mem) {
+int sp_welch_dist_flush(int *ndone) {
     if (ensure_init()) return -1;
-    if (have) *have = 0;
+    if (ndone) *ndone = 0;
     ApiLock lk;
-    if (!gcomm.comm) return fail("sp_welch_dist_flush: no communicator (sp_comm_init)");
-    const int o = 1 - gcomm.cur;                      // the slot submitted last
-    if (!gcomm.slot[o].valid) return 0;
-    if (!pxx_out) return fail("sp_welch_dist_flush: a step is pending and pxx_out is null");
-    const int nb = nbins_host((int)gcomm.slot[o].win.size(), gcomm.slot[o].sided);
-    double *out_d = pxx_out;
-    if (!mem) {
-        if (g.out0.ensure(sizeof(double) * (size_t)nb)) return -1;
-        out_d = (double *)g.out0.p;
+    const int64_t k = geng.nsub;
+    if (k == 0 || !geng.epi) return 0;
+    const int s = (int)((k - 1) & 1);                 // the slot submitted last
+    int done = 1;
+    if (geng.with_comm) {
+        // the last step's state still waits for its apply (B-ordered behind its collective); the step before it was applied by the
+        // last step's epilogue launch and becomes valid with the same wait
+        if (engine_apply_locked(s)) return -1;
+        HIPCHK(hipEventRecord(geng.ev_epi[s], geng.epi));
+        if (k >= 2) done = 2;
     }
-    if (dist_apply_locked(o, out_d)) return -1;
-    if (!mem) {
-        HIPCHK(hipMemcpyAsync(pxx_out, out_d, sizeof(double) * (size_t)nb, hipMemcpyDeviceToHost, g.stream));
-        HIPCHK(hipStreamSynchronize(g.stream));
-    }
-    if (have) *have = 1;
+    HIPCHK(hipStreamWaitEvent(g.stream, geng.ev_epi[s], 0));
+    geng.slot[0].busy = geng.slot[1].busy = false;
+    geng.nsub = 0;
+    if (ndone) *ndone = done;
     return 0;
 }
 
 int sp_welch_psd_dist(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft, int hop, int64_t nframes,
-                      int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_out, int mem) {
+                      int64_t nmean, int64_t frames_total, int sided, double scale, double *pxx_out) {
     {
         std::lock_guard<std::mutex> lk(g.mu);
-        if (gcomm.comm && (gcomm.slot[0].valid || gcomm.slot[1].valid))
-            return fail("sp_welch_psd_dist: a pipelined step is pending (sp_welch_dist_flush first)");
+        if (geng.nsub) return fail("sp_welch_psd_dist: streaming steps are in flight (sp_welch_dist_flush first)");
     }
-    int have = 0;
-    if (sp_welch_dist_submit(x, x_dtype, nsig, win, nfft, hop, nframes, nmean, frames_total, sided, scale, nullptr, &have, mem))
-        return -1;
-    return sp_welch_dist_flush(pxx_out, &have, mem);
+    int n = 0;
+    if (sp_welch_dist_submit(x, x_dtype, nsig, win, nfft, hop, nframes, nmean, frames_total, sided, scale, pxx_out, &n)) return -1;
+    return sp_welch_dist_flush(&n);
 }
 
 int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch, int64_t y_ld, const float *win,

@@ -119,27 +119,40 @@ def native_comm_init(group=None, device=None):
 
 
 class NativeWelchPipeline(object):
-    """WelchPipeline with the whole step inside libspectral (sp_welch_dist_submit / sp_welch_dist_flush): export kernels,
-    ncclAllReduce on the library's collective stream behind an event, and the apply of the previous step behind that step's
-    event -- one ctypes call per step, no torch.distributed work object, no host synchronisation (host cost per step ~25 us
-    against ~75-100 us for the torch.distributed form: at 2^25 samples per GPU the kernels of a step take ~0.09 ms, so the
-    Python form is host-bound there).  Needs native_comm_init.  Same interface as WelchPipeline."""
+    """WelchPipeline with the whole step inside libspectral (sp_welch_dist_submit / sp_welch_dist_flush): one ctypes call per
+    step, no torch.distributed work object, no host synchronisation.  The main kernel runs on torch's current stream; the
+    epilogue (column sums + finish: ~16 us, a third of a 2^25-sample shard's step) and -- with a communicator
+    (native_comm_init) -- the RCCL all-reduce of the shard state run on the library's own stream BESIDE the next step's main
+    kernel.  Works without a communicator too (one GPU: the epilogue overlap alone).  Same interface as WelchPipeline, except
+    that a result may arrive two submits late: submit() returns the newest PSD that became valid (or None), flush() the last
+    one, flush_all() every outstanding one in order."""
 
     def __init__(self, win, plan, scale=1.0, sided=2):
         self.win, self.plan, self.scale, self.sided = win, plan, scale, sided
-        self._dev = None
+        self._fifo = []                    # (out, x) of steps not yet reported: kept alive until the library says so
+
+    def _pop(self, n):
+        done = [self._fifo.pop(0)[0] for _ in range(min(n, len(self._fifo)))]
+        return done
 
     def submit(self, x_local):
         from . import engine as E
-        self._dev = x_local.device
         p = self.plan
-        return E.welch_dist_submit(x_local, self.win, p.hop, p.frames, p.own_samples, p.frames_total, self.sided, self.scale)
+        out, xs, nd = E.welch_dist_submit(x_local, self.win, p.hop, p.frames, p.own_samples, p.frames_total, self.sided, self.scale)
+        self._fifo.append((out, xs))
+        done = self._pop(nd)
+        return done[-1] if done else None
+
+    def flush_all(self):
+        from . import engine as E
+        if not self._fifo:
+            return []
+        E.welch_dist_flush()
+        return self._pop(len(self._fifo))
 
     def flush(self):
-        from . import engine as E
-        if self._dev is None:
-            return None
-        return E.welch_dist_flush(self.plan.nfft, self.sided, self._dev)
+        done = self.flush_all()
+        return done[-1] if done else None
 
 
 def welch_psd_sharded_two_step(x_local, win, plan, scale=1.0, sided=2, group=None):

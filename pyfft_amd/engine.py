@@ -250,26 +250,26 @@ def comm_destroy():
 
 
 def welch_dist_submit(x, win, hop, nframes, nmean, frames_total, sided=SIDED_TWO, scale=1.0):
-    """One step of the sharded Welch PSD with the host out of the loop (sp_welch_dist_submit): this shard's export kernels,
-    the RCCL all-reduce of its state on the library's collective stream, and the apply of the PREVIOUS submit.  x: device
-    tensor (this rank's shard).  Returns the previous step's PSD of the whole stream (float64 [nbins], device) or None."""
+    """One step of the streaming Welch PSD (sp_welch_dist_submit): the main kernel on torch's current stream, the epilogue (and
+    with a communicator the RCCL all-reduce of the shard's state) on the library's own stream beside the NEXT step's main kernel.
+    x: device tensor (this rank's shard).  Returns (out, ndone): `out` = the tensor that will hold THIS step's PSD of the whole
+    stream (float64 [nbins], device), `ndone` = how many earlier steps' tensors became valid with this call.  Keep x and out
+    alive until reported (NativeWelchPipeline does the bookkeeping)."""
     w = _win32(win)
     _bind_stream(x)
     xs = _torch_samples(x)
     out = torch.empty(nbins(w.size, sided), dtype=torch.float64, device=xs.device)
-    have = _ffi.C.c_int(0)
+    nd = _ffi.C.c_int(0)
     check(lib().sp_welch_dist_submit(ptr(xs.data_ptr()), _tcode(xs), xs.numel(), ptr(w), w.size, int(hop), int(nframes),
-                                     int(nmean), int(frames_total), sided, float(scale), ptr(out.data_ptr()),
-                                     _ffi.C.byref(have), 1))
-    return out if have.value else None
+                                     int(nmean), int(frames_total), sided, float(scale), ptr(out.data_ptr()), _ffi.C.byref(nd)))
+    return out, xs, nd.value
 
 
-def welch_dist_flush(nfft, sided, device):
-    """finish the last welch_dist_submit: its PSD (device tensor) or None when nothing is pending"""
-    out = torch.empty(nbins(nfft, sided), dtype=torch.float64, device=device)
-    have = _ffi.C.c_int(0)
-    check(lib().sp_welch_dist_flush(ptr(out.data_ptr()), _ffi.C.byref(have), 1))
-    return out if have.value else None
+def welch_dist_flush():
+    """finish every step in flight; returns how many outputs became valid"""
+    nd = _ffi.C.c_int(0)
+    check(lib().sp_welch_dist_flush(_ffi.C.byref(nd)))
+    return nd.value
 
 
 def welch_finish(nfft, mean, frames_total, sided=SIDED_TWO, scale=1.0, like=None):

@@ -76,6 +76,34 @@ def main():
     out["csd_compact_vs_local"] = float(torch.max(torch.abs(gc - g0)).item()) / pk
     out["csd_full_vs_local"] = float(torch.max(torch.abs(gf - g0)).item()) / pk
     out["csd_compact_vs_oracle"] = float(np.max(np.abs(gc.cpu().numpy() - refm))) / pk
+    # (3b) the streaming engine WITHOUT a communicator (one GPU: the epilogue of step k beside the main kernel of step k + 1)
+    from pyfft_amd.dist import NativeWelchPipeline as _NP
+    spipe = _NP(win, plan, scale=1.0 / S2, sided=E.SIDED_TWO)
+    got = []
+    for x in xs + xs:                              # ten steps: both scratch sets are reused several times
+        r = spipe.submit(x)
+        if r is not None:
+            got.append(r)
+    got.extend(spipe.flush_all())
+    worst = 0.0
+    for x, g in zip(xs + xs, got):
+        one = E.welch_psd(x, win, hop, plan.frames, detrend=True, sided=E.SIDED_TWO, scale=1.0 / S2)
+        worst = max(worst, float(torch.max(torch.abs(g - one) / (2e-4 * torch.abs(one) + 1e-6 * one.max())).item()))
+    out["stream_steps"] = len(got)
+    out["stream_vs_single_call"] = worst
+    # real input (two frames per transform) and a non-cosine window (two-launch epilogue on the engine's stream)
+    xr = [torch.randn(total, device=dev) + 0.5 * k for k in range(3)]
+    from pyfft_amd.windows import get_window as _gw
+    wk2 = np.asarray(_gw(("kaiser", 5.0), nfft, fftbins=True), dtype=np.float64)
+    worst = 0.0
+    for w_ in (win, wk2):
+        rp = _NP(w_, plan, scale=1.0, sided=E.SIDED_TWO)
+        res = [r for r in (rp.submit(x) for x in xr) if r is not None] + rp.flush_all()
+        assert len(res) == 3
+        for x, g in zip(xr, res):
+            one = E.welch_psd(x, w_, hop, plan.frames, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+            worst = max(worst, float(torch.max(torch.abs(g - one) / (2e-4 * torch.abs(one) + 1e-6 * one.max())).item()))
+    out["stream_real_and_kaiser"] = worst
     # (4) the same pipeline with the collective issued by libspectral itself (sp_comm_init + sp_welch_dist_submit/flush)
     from pyfft_amd.dist import native_comm_init, NativeWelchPipeline
     out["native_comm"] = list(native_comm_init(device=0))
@@ -86,7 +114,7 @@ def main():
         r = npipe.submit(x)
         if r is not None:
             got.append(r)
-    got.append(npipe.flush())
+    got.extend(npipe.flush_all())                # (with a communicator results arrive two submits late: two are left)
     assert npipe.flush() is None
     worst = 0.0
     for x, g in zip(xs, got):
@@ -98,7 +126,7 @@ def main():
     from pyfft_amd.windows import get_window
     wk = np.asarray(get_window(("kaiser", 8.0), nfft, fftbins=True), dtype=np.float64)
     pk = NativeWelchPipeline(wk, plan, scale=1.0, sided=E.SIDED_TWO)
-    pk.submit(xs[0])
+    assert pk.submit(xs[0]) is None
     gk = pk.flush()
     onek = E.welch_psd(xs[0], wk, hop, plan.frames, detrend=True, sided=E.SIDED_TWO, scale=1.0)
     out["native_kaiser_vs_single_call"] = float(torch.max(torch.abs(gk - onek) / (2e-4 * torch.abs(onek) + 1e-6 * onek.max())).item())

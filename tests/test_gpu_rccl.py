@@ -33,6 +33,8 @@ def test_rccl_world1_sharded_paths():
     assert d["csd_compact_vs_local"] <= 2e-7            # one complex64 rounding of a float32-accurate matrix
     assert d["csd_full_vs_local"] <= 1e-12
     assert d["csd_compact_vs_oracle"] <= 2e-4
+    # the streaming engine without a communicator: epilogue on the library's stream beside the next main kernel
+    assert d["stream_steps"] == 10 and d["stream_vs_single_call"] <= 1.0 and d["stream_real_and_kaiser"] <= 1.0
     # the collective issued by libspectral on its own stream (sp_comm_init, sp_welch_dist_submit / _flush)
     assert d["native_comm"] == [1, 0] and d["native_comm_info"] == [1, 0]
     assert d["native_pipeline_steps"] == 5

@@ -36,8 +36,11 @@ def main():
     ap.add_argument("--sizes", type=int, nargs="+", default=[28, 27, 26, 25, 24])
     ap.add_argument("--env", nargs="*", default=[], help="NAME=VALUE pairs passed to bench.py (A/B of a build knob)")
     args = ap.parse_args()
-    extra = dict(kv.split("=", 1) for kv in args.env)
-    for label, fd in (("single-GPU path (sp_welch_psd)", False), ("sharded path, RCCL group of one rank (export -> all-reduce -> apply)", True)):
+    extra0 = dict(kv.split("=", 1) for kv in args.env)
+    for label, fd, env2 in (("single GPU, one sp_welch_psd call per step (SP_BENCH_STREAM=0)", False, {"SP_BENCH_STREAM": "0"}),
+                            ("single GPU, steps streamed through sp_welch_dist_submit (epilogue beside the next main kernel)", False, {}),
+                            ("sharded path, RCCL group of one rank (export -> all-reduce -> apply, streamed)", True, {})):
+        extra = dict(extra0, **env2)
         print("== %s%s" % (label, ("  [" + " ".join(args.env) + "]") if args.env else ""))
         print("%6s %12s %12s %12s %12s %10s" % ("log2n", "ms/step", "kernel ms", "host ms", "Msamples/s", "roof frac"))
         ns, ts, ks = [], [], []
