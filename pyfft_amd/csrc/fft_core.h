@@ -219,6 +219,51 @@ template <bool TWD, class Store> __device__ __forceinline__ void dft16s_es(cf (&
 #undef SP_ES_OUT
 }
 
+// The untwiddled first pass with the WINDOW folded into its first radix-4 stage: the inputs are the raw samples r[t] and
+// the window values w[t]; instead of 32 multiplications v = w r followed by 16 additions per butterfly, the pair sums are
+// formed as a' = w_a r_a, t0 = fma(w_c, r_c, a'), t1 = fma(-w_c, r_c, a') (and b', t2, t3 alike): 20 instructions per
+// butterfly instead of 8 + 16 -- 16 VALU instructions per frame and thread less (585 instead of 601 at 4096 points).
+__device__ __forceinline__ void dft4w(cf &a, cf &b, cf &c, cf &d, float wa, float wb, float wc, float wd) {
+    const cf pa = mk(wa * a.x, wa * a.y), pb = mk(wb * b.x, wb * b.y);
+    const cf t0 = mk(fmaf(wc, c.x, pa.x), fmaf(wc, c.y, pa.y));
+    const cf t1 = mk(fmaf(-wc, c.x, pa.x), fmaf(-wc, c.y, pa.y));
+    const cf t2 = mk(fmaf(wd, d.x, pb.x), fmaf(wd, d.y, pb.y));
+    const cf t3 = mk(fmaf(-wd, d.x, pb.x), fmaf(-wd, d.y, pb.y));
+    a = t0 + t2;
+    c = t0 - t2;
+    b = mk(t1.x + t3.y, t1.y - t3.x);           // t1 - i t3
+    d = mk(t1.x - t3.y, t1.y + t3.x);
+}
+template <class Store> __device__ __forceinline__ void dft16s_es_win(cf (&x)[16], const float (&w)[16], Store store) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dft4w(x[b], x[b + 4], x[b + 8], x[b + 12], w[b], w[b + 4], w[b + 8], w[b + 12]);
+    x[5] = rot_tan(x[5], SP_T16);
+    x[9] = mk(x[9].x + x[9].y, x[9].y - x[9].x);
+    x[13] = rot_tan(x[13], SP_T316);
+    x[6] = mk(x[6].x + x[6].y, x[6].y - x[6].x);
+    x[10] = mk(x[10].y, -x[10].x);
+    x[14] = mk(x[14].x - x[14].y, x[14].y + x[14].x);
+    x[7] = rot_tan(x[7], SP_T316);
+    x[11] = mk(x[11].x - x[11].y, x[11].y + x[11].x);
+    x[15] = rot_tan(x[15], SP_T16);
+    __builtin_amdgcn_sched_barrier(0);
+#define SP_ES_OUT(c)                                                                                                 \
+    store(c, x[4 * c]);                                                                                              \
+    store(c + 4, x[4 * c + 1]);                                                                                      \
+    store(c + 8, x[4 * c + 2]);                                                                                      \
+    store(c + 12, x[4 * c + 3]);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);
+    dft4<false>(x[0], x[1], x[2], x[3]);
+    SP_ES_OUT(0)
+    dft4s(x[4], x[5], x[6], x[7], SP_C16, SP_C8, SP_S16 / SP_C16);
+    SP_ES_OUT(1)
+    dft4s(x[8], x[9], x[10], x[11], SP_C8, 1.f, -1.f);
+    SP_ES_OUT(2)
+    dft4s(x[12], x[13], x[14], x[15], SP_S16, -SP_C8, -SP_C16 / SP_S16);
+    SP_ES_OUT(3)
+#undef SP_ES_OUT
+}
+
 // ---- the same butterflies in packed fp32 (v_pk_fma_f32 / v_pk_add_f32), SP_PACKED=1 ---------------------------------
 // A complex value is one 64-bit register pair and every butterfly line is ONE packed instruction; the swap of re/im,
 // the broadcast of a real scale out of a register pair and the signs ride in the op_sel / neg modifiers (inline asm:
@@ -635,6 +680,15 @@ template <int N, bool TW1LDS = false, bool RM = false> struct WgFft {
         auto store = [&](int k, cf val) __attribute__((always_inline)) { lds[phys<P>(base + k * NS)] = val; };
         if constexpr (P > 0) dft16s_es<true>(v, t16[P - 1], store);
         else dft16s_es<false>(v, t16[0], store);
+    }
+
+    // pass 0 on RAW samples with the window folded into the first radix-4 stage (dft16s_es_win), scatter folded in
+    __device__ __forceinline__ void bfly_scatter_win(cf (&v)[R], const float (&w)[R], cf *lds, int tid) const {
+        static_assert(R == 16, "radix-16 first pass");
+        constexpr int NS = PL::ns(0);
+        const int base = (tid / NS) * (NS * 16) + (tid % NS);
+        auto store = [&](int k, cf val) __attribute__((always_inline)) { lds[phys<0>(base + k * NS)] = val; };
+        dft16s_es_win(v, w, store);
     }
 
     template <int P, bool SINGLE> __device__ __forceinline__ void pass(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {

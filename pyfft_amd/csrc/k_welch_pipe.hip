@@ -39,6 +39,10 @@
 #ifndef SP_PIPE_AHEAD
 #define SP_PIPE_AHEAD 2
 #endif
+// SP_PIPE_WINFOLD=1: the front role folds the window into the first radix-4 stage (dft16s_es_win: 16 VALU less per frame)
+#ifndef SP_PIPE_WINFOLD
+#define SP_PIPE_WINFOLD 1
+#endif
 #ifndef SP_PIPE_RM
 #define SP_PIPE_RM 0          // 1: first exchange image [thread][16] (fft_core.h, WgFft RM): 16-byte scatter writes
 #endif
@@ -188,9 +192,15 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             issue_chunk(fill, g0 + i + 2);
             __builtin_amdgcn_sched_barrier(0);
             cf v[R];
+            if constexpr (SP_PIPE_WINFOLD && !SP_PIPE_RM && !SP_ABLATE) {
 #pragma unroll
-            for (int t = 0; t < R; ++t) v[t] = mk(w[t] * cur[t], HB ? w[t] * (t < R / 2 ? cur[t + R / 2] : nxt[t - R / 2]) : 0.f);
-            f.template bfly_scatter<0>(v, img, tid);
+                for (int t = 0; t < R; ++t) v[t] = mk(cur[t], HB ? (t < R / 2 ? cur[t + R / 2] : nxt[t - R / 2]) : 0.f);
+                f.bfly_scatter_win(v, w, img, tid);
+            } else {
+#pragma unroll
+                for (int t = 0; t < R; ++t) v[t] = mk(w[t] * cur[t], HB ? w[t] * (t < R / 2 ? cur[t + R / 2] : nxt[t - R / 2]) : 0.f);
+                f.template bfly_scatter<0>(v, img, tid);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (ONEPASS) {
                 // last hop-block of frame 2q (second half of the chunk) and of frame 2q + 1 (first half of the next one)
@@ -300,8 +310,9 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             __builtin_amdgcn_sched_barrier(0);
 #endif
             cf v[R];
+            constexpr bool WINFOLD = SP_PIPE_WINFOLD && SPREAD && !SP_PIPE_RM;
 #pragma unroll
-            for (int t = 0; t < R; ++t) v[t] = w[t] * raw[t];
+            for (int t = 0; t < R; ++t) v[t] = WINFOLD ? raw[t] : w[t] * raw[t];
             if constexpr (SPREAD) {
             // the other three quarters of the loads leave behind the store groups of the butterfly: a CU keeps about
             // 24-32 KiB of misses in flight (tools/ubench/stream_mlp.hip) and HBM latency is about one period, so a burst of
@@ -312,7 +323,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
                     img[F::template phys<0>(tid * 16 + k)] = val;
                     if (k >= 12 && k < 15) issue_part(fill, i + AHEAD, (k - 11) * (SHIFT / 4), (k - 10) * (SHIFT / 4));
                 };
-                dft16s_es<false>(v, f.t16[0], store);
+                if constexpr (WINFOLD) dft16s_es_win(v, w, store);
+                else dft16s_es<false>(v, f.t16[0], store);
             }
             } else {
 #if SP_PIPE_ES && !SP_ABLATE
