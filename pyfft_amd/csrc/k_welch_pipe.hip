@@ -293,8 +293,12 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
         auto issue = [&](cf (&dst)[SHIFT], int64_t q) __attribute__((always_inline)) { issue_part(dst, q, 0, SHIFT); };
         // two frames ahead + spread loads up to hop = nfft/2; at hop = nfft (16 new slots per frame) a second set of incoming
         // registers does not fit (56 spills): one frame ahead, one burst
-        constexpr int AHEAD = (SP_PIPE_AHEAD == 2 && SHIFT <= 8) ? 2 : 1;
-        constexpr bool SPREAD = SP_PIPE_SPREAD && AHEAD == 2 && !SP_ABLATE;
+        // (SP_PIPE_AHEAD=3: three frames ahead -- the new slots are then in flight for two full periods before their first use;
+        //  with two, the groups issued late in a period (SPREAD) have little more than one, about the loaded HBM latency.
+        //  Round 3: not usable as written -- the six-fold unrolled rotation of three register sets compiles to 168 VGPRs with
+        //  47 spilled; kept behind the knob)
+        constexpr int AHEAD = (SP_PIPE_AHEAD >= 2 && SHIFT <= 8) ? (SP_PIPE_AHEAD >= 3 ? 3 : 2) : 1;
+        constexpr bool SPREAD = SP_PIPE_SPREAD && AHEAD >= 2 && !SP_ABLATE;
         // one period: loads of frame i + AHEAD go out first and are consumed AHEAD periods later (`fill`); `take` holds the
         // new slots of frame i + 1
         auto frame = [&](int64_t i, cf *img, cf (&fill)[SHIFT], cf (&take)[SHIFT]) __attribute__((always_inline)) {
@@ -346,7 +350,33 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             for (int s = 0; s < SHIFT; ++s) raw[KEEP + s] = take[s] - mu;
         };
         int64_t i = 0;
-        if constexpr (AHEAD == 2) {
+        if constexpr (AHEAD == 3) {
+            // three rotating sets: at period i `fill` = S[i % 3] receives frame i + 3, `take` = S[(i + 1) % 3] holds frame i + 1
+            cf s0[SHIFT], s1[SHIFT], s2[SHIFT];
+            issue(s1, 1);
+            issue(s2, 2);
+            for (; i + 5 < trips; i += 6) {
+                frame(i, imgA, s0, s1);
+                PIPE_SYNC();
+                frame(i + 1, imgA + IMG, s1, s2);
+                PIPE_SYNC();
+                frame(i + 2, imgA, s2, s0);
+                PIPE_SYNC();
+                frame(i + 3, imgA + IMG, s0, s1);
+                PIPE_SYNC();
+                frame(i + 4, imgA, s1, s2);
+                PIPE_SYNC();
+                frame(i + 5, imgA + IMG, s2, s0);
+                PIPE_SYNC();
+            }
+            for (; i < trips; ++i) {                   // i is a multiple of 6 at entry of this tail: rotation state i % 3
+                cf *img = (i & 1) ? imgA + IMG : imgA;
+                if (i % 3 == 0) frame(i, img, s0, s1);
+                else if (i % 3 == 1) frame(i, img, s1, s2);
+                else frame(i, img, s2, s0);
+                PIPE_SYNC();
+            }
+        } else if constexpr (AHEAD == 2) {
             cf nxa[SHIFT], nxb[SHIFT];
             issue(nxa, 1);
             for (; i + 1 < trips; i += 2) {
