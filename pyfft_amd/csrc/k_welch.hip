@@ -212,22 +212,26 @@ int launch_op_finish(LaunchCtx c, const void *x, bool cplx, const float *trend, 
 
 int launch_op_fused(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, const float *partial,
                     const cf *spartial, int64_t G, int n, int hop, int64_t nframes, int64_t nmean, OnePass st, unsigned *ticket,
-                    CogLobe lb, const double *mean_in, int sided, double scale, double *out, bool export_state, OpPrev prev, bool light) {
+                    CogLobe lb, const double *mean_in, int sided, double scale, double *out, bool export_state, OpPrev prev, bool light,
+                    double cola_c) {
     if (n % hop != 0 || n / hop > 4 || (hop & (hop - 1)) != 0 || n % 32 != 0 || (2 * hop) % 32 != 0 || lb.K < 0 || lb.K > 3 || n < 2 * lb.K + 2)
         return -1;
+    const bool lobeb = cola_c > 0.0;             // the main kernel left lobe sums (k_welch_pipe mode 9), not block sums
     const int wg = light ? SP_OPF_WG_LIGHT : SP_OPF_WG;
-    const dim3 grid(n / 32 + (2 * hop) / 32), block(wg);
+    const dim3 grid(n / 32 + (lobeb ? 0 : (2 * hop) / 32)), block(wg);
     const double ang = -2.0 * M_PI * (double)wg / (double)n;                   // the bin-to-bin rotation of the last block's twiddles
     const double step_c = cos(ang), step_s = sin(ang);
-#define FUSED_(CP, EX, EE, LT)                                                                         \
-    hipLaunchKernelGGL((k_op_fused<CP, EX, EE, LT>), grid, block, 0, c.stream, partial, n, st.A, reinterpret_cast<const float *>(spartial), \
-                       hop, st.Sl, G, ticket, x, trend, win, lb, mean_in, nframes, nmean, sided, scale, out, st.sym, prev, step_c, step_s)
+#define FUSED_(CP, EX, EE, LT, LB)                                                                     \
+    hipLaunchKernelGGL((k_op_fused<CP, EX, EE, LT, LB>), grid, block, 0, c.stream, partial, n, st.A, reinterpret_cast<const float *>(spartial), \
+                       hop, st.Sl, G, ticket, x, trend, win, lb, mean_in, nframes, nmean, sided, scale, out, st.sym, prev, step_c, step_s, cola_c)
 #define FUSED_E_(CP, EX)                                                                               \
     {                                                                                                 \
-        if (light) {                                                                                  \
-            if (n / hop <= 2) FUSED_(CP, EX, 1, true); else FUSED_(CP, EX, 3, true);                   \
+        if (lobeb) {                                                                                  \
+            if (light) FUSED_(CP, EX, 1, true, true); else FUSED_(CP, EX, 1, false, true);             \
+        } else if (light) {                                                                           \
+            if (n / hop <= 2) FUSED_(CP, EX, 1, true, false); else FUSED_(CP, EX, 3, true, false);     \
         } else {                                                                                      \
-            if (n / hop <= 2) FUSED_(CP, EX, 1, false); else FUSED_(CP, EX, 3, false);                 \
+            if (n / hop <= 2) FUSED_(CP, EX, 1, false, false); else FUSED_(CP, EX, 3, false, false);   \
         }                                                                                             \
     }
     if (cplx) {

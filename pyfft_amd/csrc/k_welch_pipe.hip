@@ -55,8 +55,15 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
                                                      int64_t nframes, int64_t fpg, float *__restrict__ trend_in, XfTables tb,
                                                      float *__restrict__ partial, cf *__restrict__ spartial, int64_t x_cs, int gpr) {
     constexpr int N = 4096;
-    constexpr bool RP = MODE >= 3 && MODE != 8;         // real input, two frames per transform (modes 3: plain, 4: one-pass detrend, 5: spectra)
-    constexpr bool ONEPASS = MODE == 1 || MODE == 4 || MODE == 7 || MODE == 8, COG = MODE == 2 || MODE == 8;   // (7: mode 5, 8: mode 2, with the one-pass block sums)
+    constexpr bool RP = MODE >= 3 && MODE != 8 && MODE != 9;         // real input, two frames per transform (modes 3: plain, 4: one-pass detrend, 5: spectra)
+    constexpr bool ONEPASS = MODE == 1 || MODE == 4 || MODE == 7 || MODE == 8 || MODE == 9, COG = MODE == 2 || MODE == 8;   // (7: mode 5, 8: mode 2, with the one-pass block sums)
+    // mode 9 = mode 1 for windows whose spectrum is confined to the bins -3 .. 3 AND that add up to a constant at this hop
+    // (COLA: Hann, Hamming at 50 / 75 % ...): what the epilogue needs of sum_g X_g are those 7 bins, which the BACK role has in
+    // registers anyway (bins 0..3 in slot 0 of threads 0..3, bins N-3..N-1 in slot 15 of threads 253..255): 4 additions per
+    // frame there instead of the front role's 16 for the block sums, no block sums written, and the signal's plain sum
+    // follows from the DC bin, sum_g X_g[0] = sum_i cov(i) (x[i] - mu0) with cov = c but for the two edges (k_op_fused<LOBEB>).
+    // `spartial` receives lobeB[group][8] (ks = -3 .. 3 at index ks + 3) instead of the block sums.
+    constexpr bool LOBE = MODE == 9;
     // mode 5: no accumulation -- the packed pair spectrum Z = X_2q + i X_2q+1 of every frame pair is WRITTEN, all N bins, for the
     // CSD-matrix contraction: Zs[pair of pairs][group of 8 bins][channel slot of 64][8 bins][2 pairs] (k_csdm_bf16's layout with
     // "frames" = pairs).  The contraction of the PACKED spectra, H[k] = sum Z_i[k] conj Z_j[k], gives the matrix by the mirror
@@ -343,7 +350,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             // off the critical path of the period: the stores above drain while these issue
 #pragma unroll
             for (int s = 0; s < SHIFT; ++s)
-                if constexpr (ONEPASS) sacc[s] = sacc[s] + raw[KEEP + s];
+                if constexpr (ONEPASS && !LOBE) sacc[s] = sacc[s] + raw[KEEP + s];
 #pragma unroll
             for (int t = 0; t < KEEP; ++t) raw[t] = raw[t + SHIFT];
 #pragma unroll
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
         for (int d = 0; d < DRAIN; ++d) PIPE_SYNC();
 #pragma unroll
         for (int s = 0; s < SHIFT; ++s)
-            if constexpr (ONEPASS) spartial[gid * hop + tid + T * s] = sacc[s];
+            if constexpr (ONEPASS && !LOBE) spartial[gid * hop + tid + T * s] = sacc[s];
     } else if (role == 1) {
         if constexpr (SP_PIPE_PRIO) __builtin_amdgcn_s_setprio((SP_PIPE_PRIO / 10) % 10);
         // period p: the gather of frame p-1 is ISSUED first and lands while the butterflies of frame p-2 (gathered one period
@@ -443,6 +450,7 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
         float acc[R];
 #pragma unroll
         for (int t = 0; t < R; ++t) acc[t] = 0.f;
+        cf bs_lo = mk(0.f, 0.f), bs_hi = mk(0.f, 0.f);          // LOBE: sum over the frames of bin tid (slot 0) and bin tid + 15 T (slot 15)
         // SPEC: offset (16-byte units) of bin k = tid + T t inside a pair-of-pairs block: (k / 8) 512 + k % 8 = zlo + 16384 t
         const unsigned zlo = (unsigned)((tid >> 3) * 512 + (tid & 7));
         cf held[SPEC ? R : 1];                 // SPEC: the spectrum of the even pair, waiting for its odd partner
@@ -513,6 +521,10 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
                 } else {
 #pragma unroll
                     for (int t = 0; t < R; ++t) acc[t] = fmaf(use[t].y, use[t].y, fmaf(use[t].x, use[t].x, acc[t]));
+                    if constexpr (LOBE) {
+                        bs_lo = bs_lo + use[0];
+                        bs_hi = bs_hi + use[R - 1];
+                    }
                 }
             }
             PIPE_SYNC();
@@ -524,6 +536,11 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
         if constexpr (!COG && !SPEC) {
 #pragma unroll
             for (int t = 0; t < R; ++t) partial[gid * N + tid + T * t] = acc[t];
+            if constexpr (LOBE) {
+                if (tid <= 3) spartial[gid * 8 + 3 + tid] = bs_lo;
+                if (tid >= T - 3) spartial[gid * 8 + 3 - (T - tid)] = bs_hi;
+                if (tid == 4) spartial[gid * 8 + 7] = mk(0.f, 0.f);
+            }
         }
     }
 #if SP_PIPE_TIMING
@@ -588,6 +605,11 @@ int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, i
         else return -1;
     } else if (mode == 2) {
         if (cplx) { PIPE_S_(true, 2) } else { PIPE_S_(false, 2) }
+    } else if (mode == 9) {
+        // mode 1 with the lobe sums in the back role (hop 2048 / 1024 only, as the one-pass front role)
+        if (!spartial || shift == 16) return -1;
+        if (shift == 8) { if (cplx) PIPE_(true, 8, 9) else PIPE_(false, 8, 9) }
+        else { if (cplx) PIPE_(true, 4, 9) else PIPE_(false, 4, 9) }
     } else if (spartial) {
         if (cplx) { PIPE_S_(true, 1) } else { PIPE_S_(false, 1) }
     } else {

@@ -2049,7 +2049,13 @@ struct OpPrev {                 // the previous step of the pipelined sharded PS
 // and chunk: more round trips for the last block, which nobody waits for.
 #define SP_OPF_WG 512
 #define SP_OPF_WG_LIGHT 256
-template <bool CPLX, bool EXPORT, int E, bool LIGHT = false>
+// LOBEB: the main kernel ran in mode 9 (k_welch_pipe): no block sums -- m1 is lobeB[G][8], the groups' sums of the spectra at the
+// bins ks = -3 .. 3 (index ks + 3), and the window adds up to the constant cola_c at this hop.  B[ks] = sum_G lobeB; the plain sum
+// of the samples follows from the DC bin: B[0] = sum_i cov(i) (x[i] - mu0), cov(i) = sum of the window values of the frames that
+// cover sample i = cola_c everywhere but within N - H samples of the two ends, so sum_i (x[i] - mu0) = (B[0] + sum_edges (cola_c -
+// cov(i)) (x[i] - mu0)) / cola_c -- a few thousand samples read by the last block.  No column sums of block sums (half of phase 1),
+// no c[n] rebuild (the last block's big round trip).
+template <bool CPLX, bool EXPORT, int E, bool LIGHT = false, bool LOBEB = false>
 static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
     __attribute__((amdgpu_waves_per_eu(LIGHT ? 5 : 2, LIGHT ? 8 : 2))) void k_op_fused(const float *__restrict__ m0, int N, double *__restrict__ Acol,
                                                                 const float *__restrict__ m1, int H, double *__restrict__ Sl,
@@ -2058,7 +2064,7 @@ static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
                                                                 const float *__restrict__ win, CogLobe lb,
                                                                 const double *__restrict__ mean_in, int64_t M, int64_t nmean,
                                                                 int sided, double scale, double *__restrict__ out, int sym,
-                                                                OpPrev prev, double step_c, double step_s) {
+                                                                OpPrev prev, double step_c, double step_s, double cola_c) {
     constexpr int WG = LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG, NW = WG / 64, NSL = WG / 8;
     OPF_STAMP(ts_start);
     __shared__ double sh[NW][32];
@@ -2165,6 +2171,37 @@ static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
     }
     constexpr int NPT = LIGHT ? 2 : ((E > 1 && CPLX) ? 4 : 8);    // bins per thread and chunk: N <= 4096 is one chunk, one round trip (hop = N/4, complex: two)
     double ak[NPT];                                 // raw sums A[k] of the thread's bins (kept for the output loop)
+    if constexpr (LOBEB) {
+        const cf *__restrict__ lobeB = reinterpret_cast<const cf *>(m1);
+        for (int64_t g = threadIdx.x; g < G; g += WG) {
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const cf v = lobeB[g * 8 + q];
+                acc[2 + 2 * q] += (double)v.x;
+                acc[3 + 2 * q] += (double)v.y;
+            }
+        }
+        if (EXPORT || !mean_in) {
+            // the two edges, where fewer than r frames cover a sample: (cola_c - cov(i)) (x[i] - mu0) / cola_c
+            const int64_t nhead = (int64_t)(r - 1) * H, mh = M * (int64_t)H;
+            const int64_t tail0 = mh > nhead ? mh : nhead;
+            const double ic = 1.0 / cola_c;
+            for (int side = 0; side < 2; ++side) {
+                const int64_t i0 = side ? tail0 : 0, i1 = side ? cov : (nhead < cov ? nhead : cov);
+                for (int64_t i = i0 + threadIdx.x; i < i1; i += WG) {
+                    int64_t ghi = i >> hs;
+                    ghi = ghi < M - 1 ? ghi : M - 1;
+                    const int64_t glo = i >= N ? ((i - N) >> hs) + 1 : 0;
+                    double cv = 0.0;
+                    for (int64_t gg = glo; gg <= ghi; ++gg) cv += (double)win[i - (gg << hs)];
+                    const cf v = load_sample(x, i, CPLX) - mu;
+                    const double d = (cola_c - cv) * ic;
+                    acc[0] += d * (double)v.x;
+                    acc[1] += d * (double)v.y;
+                }
+            }
+        }
+    } else {
     // uniform bases + 32-bit lane offsets (scalar-base addressing: one offset register per load instead of a 64-bit address)
     const char *xh = reinterpret_cast<const char *>(x), *xt = xh + M * (int64_t)H * (CPLX ? 8 : 4);
     for (int base = 0; base < N; base += WG * NPT) {
@@ -2240,6 +2277,7 @@ static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
             s1 = ns1;
         }
     }
+    }
     OPF_STAMP(ts_math);
     // across the wave: the mean's total in double (shuffles), the lobe sums in float through DPP (no LDS round trips; they enter
     // the spectrum multiplied by d = mean - mu0: float32 is ample); across the waves: LDS
@@ -2260,7 +2298,8 @@ static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
         tot_sh[threadIdx.x] = a;
     }
     __syncthreads();
-    const double tot_r = tot_sh[0], tot_i = tot_sh[1];
+    // (LOBEB: the samples' sum = ragged end + edges / c [both in slot 0, 1] + B[0] / c)
+    const double tot_r = tot_sh[0] + (LOBEB ? tot_sh[2 + 6] / cola_c : 0.0), tot_i = tot_sh[1] + (LOBEB ? tot_sh[3 + 6] / cola_c : 0.0);
     double dr, di;
     if (!EXPORT && mean_in) {
         dr = mean_in[0] - (double)trend[0];
@@ -2271,7 +2310,7 @@ static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
     }
     OPF_STAMP(ts_red);
     const double mr = (double)mu.x, mi = (double)mu.y;
-    const bool one_chunk = N <= WG * NPT;
+    const bool one_chunk = !LOBEB && N <= WG * NPT;
     for (int base = 0; base < N; base += WG * NPT) {
 #pragma unroll
         for (int t = 0; t < NPT; ++t) {

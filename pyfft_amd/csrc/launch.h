@@ -137,7 +137,7 @@ int launch_op_apply(LaunchCtx c, const double *state, const cf *Wf, int n, int s
 int launch_op_fused(LaunchCtx c, const void *x, bool cplx, const float *trend, const float *win, const float *partial,
                     const cf *spartial, int64_t G, int n, int hop, int64_t nframes, int64_t nmean, OnePass st, unsigned *ticket,
                     CogLobe lb, const double *mean_in, int sided, double scale, double *out, bool export_state,
-                    OpPrev prev = OpPrev{nullptr, nullptr, nullptr, 0, 0.0}, bool light = false);
+                    OpPrev prev = OpPrev{nullptr, nullptr, nullptr, 0, 0.0}, bool light = false, double cola_c = 0.0);
 int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &xf, int sided, double scale, double *out,
                         int sym = 0);
 int launch_welch_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,

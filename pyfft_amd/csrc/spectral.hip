@@ -676,6 +676,38 @@ static bool cog_window_lobe(const float *win, int n, CogLobe *lb) {
 }
 
 
+// does the window add up to a constant at this hop (COLA)?  c = sum_j w[n + j hop] for every n < hop, host float64 on the float32
+// table (periodic Hann / Hamming at 50 % and 75 %: yes; Blackman at 50 %: no).  Cached under the window's content and the hop.
+static bool window_cola(const float *win, int n, int hop, double *c_out) {
+    struct Entry {
+        uint64_t key;
+        int n, hop;
+        bool ok;
+        double c;
+    };
+    static std::vector<Entry> cache;
+    if (hop < 1 || n % hop != 0) return false;
+    const uint64_t h = fnv1a(win, sizeof(float) * (size_t)n, 1469598103934665603ull ^ (uint64_t)hop);
+    for (const Entry &e : cache)
+        if (e.key == h && e.n == n && e.hop == hop) {
+            *c_out = e.c;
+            return e.ok;
+        }
+    double lo = 1e300, hi = -1e300, sum = 0.0;
+    for (int i = 0; i < hop; ++i) {
+        double c = 0.0;
+        for (int j = i; j < n; j += hop) c += (double)win[j];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+        sum += c;
+    }
+    Entry e{h, n, hop, false, sum / (double)hop};
+    e.ok = e.c > 0.0 && (hi - lo) <= 2e-6 * e.c;          // (float32 table values: their own rounding leaves ~1e-7)
+    if (cache.size() < 64) cache.push_back(e);
+    *c_out = e.c;
+    return e.ok;
+}
+
 // request for the epilogue in the same call (k_op_fused: column sums + finish / export in ONE launch; taken when the window's
 // spectrum is confined to the bins -3 .. 3 -- every cosine-sum window -- unless SP_OP_UNFUSED=1): done = true on return when
 // `out` has been produced, otherwise the caller runs k_op_finish as before
@@ -761,11 +793,19 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     (void)est;                       // the main kernel estimates mu0 itself and publishes it in tb.f
 #endif
     st.sym = realpair ? 1 : 0;
+    // mode 9 of the pipeline kernel: the window's lobe bins of sum_g X_g accumulated by the BACK role (4 VALU per frame) instead of
+    // the front role's block sums (16), for cosine-sum windows that are COLA at this hop and the one-launch epilogue (SP_OP_NOLOBESUM=1
+    // keeps the block sums)
+    CogLobe lobe{};
+    double cola_c = 0.0;
+    const bool fused_ok = fo && !want_sum && !env_flag("SP_OP_UNFUSED") && cog_window_lobe(win, nfft, &lobe);
+    const bool lobesum = fused_ok && pipe && !realpair && hop != nfft && !env_flag("SP_OP_NOLOBESUM") && window_cola(win, nfft, hop, &cola_c);
+    if (!lobesum) cola_c = 0.0;
     if (pipe) {
         ProfScope ps;
         LAUNCHCHK(launch_welch_pipe(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, spartial,
-                                    realpair ? 3 : 0));
-        g.last_kernel = realpair ? "k_welch_pipe(onepass,realpair)" : "k_welch_pipe(onepass)";
+                                    realpair ? 3 : (lobesum ? 9 : 0)));
+        g.last_kernel = realpair ? "k_welch_pipe(onepass,realpair)" : (lobesum ? "k_welch_pipe(onepass,lobesum)" : "k_welch_pipe(onepass)");
     } else {
         ProfScope ps;
         LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,
@@ -779,14 +819,13 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
         HIPCHK(hipStreamWaitEvent(sl->epi, sl->ev_main, 0));
         ec = LaunchCtx{sl->epi, g.ncu};
     }
-    CogLobe lobe{};
-    if (fo && !want_sum && !env_flag("SP_OP_UNFUSED") && cog_window_lobe(win, nfft, &lobe)) {
+    if (fused_ok) {
         unsigned *ticket = get_ticket(S_ticket);
         if (!ticket) return fail("ticket allocation failed");
         if (fo->prev.st && fo->prev_wait) HIPCHK(hipStreamWaitEvent(ec.stream, fo->prev_wait, 0));
         LAUNCHCHK(launch_op_fused(ec, xd, cplx, tb.f, (const float *)win_d, partial, spartial, rp.groups, nfft, hop, nframes, nmean,
                                   st, ticket, lobe, nullptr, fo->sided, fo->scale, fo->out, fo->export_state, fo->prev,
-                                  sl != nullptr && !env_flag("SP_OPF_HEAVY")));
+                                  sl != nullptr && !env_flag("SP_OPF_HEAVY"), cola_c));
         fo->done = true;
         fo->prev_done = fo->prev.st != nullptr;
         g_pend.valid = false;

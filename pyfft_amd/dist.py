@@ -118,37 +118,47 @@ def native_comm_init(group=None, device=None):
     return world, rank
 
 
+_ENGINE_FIFO = []        # (owner, out, x) of the library's ONE streaming engine, in submit order: kept alive until reported
+
+
 class NativeWelchPipeline(object):
     """WelchPipeline with the whole step inside libspectral (sp_welch_dist_submit / sp_welch_dist_flush): one ctypes call per
     step, no torch.distributed work object, no host synchronisation.  The main kernel runs on torch's current stream; the
     epilogue (column sums + finish: ~16 us, a third of a 2^25-sample shard's step) and -- with a communicator
     (native_comm_init) -- the RCCL all-reduce of the shard state run on the library's own stream BESIDE the next step's main
     kernel.  Works without a communicator too (one GPU: the epilogue overlap alone).  Same interface as WelchPipeline, except
-    that a result may arrive two submits late: submit() returns the newest PSD that became valid (or None), flush() the last
-    one, flush_all() every outstanding one in order."""
+    that a result may arrive two submits late: submit() returns the newest of THIS pipeline's PSDs that became valid (or None),
+    flush() the last one, flush_all() every outstanding one in order.  The library has one engine: several pipeline objects
+    share it (their steps are reported to their owners in submit order)."""
 
     def __init__(self, win, plan, scale=1.0, sided=2):
         self.win, self.plan, self.scale, self.sided = win, plan, scale, sided
-        self._fifo = []                    # (out, x) of steps not yet reported: kept alive until the library says so
+        self._ready = []
 
-    def _pop(self, n):
-        done = [self._fifo.pop(0)[0] for _ in range(min(n, len(self._fifo)))]
-        return done
+    @staticmethod
+    def _report(n):
+        for _ in range(min(n, len(_ENGINE_FIFO))):
+            owner, out, _x = _ENGINE_FIFO.pop(0)
+            owner._ready.append(out)
 
     def submit(self, x_local):
         from . import engine as E
         p = self.plan
         out, xs, nd = E.welch_dist_submit(x_local, self.win, p.hop, p.frames, p.own_samples, p.frames_total, self.sided, self.scale)
-        self._fifo.append((out, xs))
-        done = self._pop(nd)
-        return done[-1] if done else None
+        _ENGINE_FIFO.append((self, out, xs))
+        self._report(nd)
+        if not self._ready:
+            return None
+        newest, self._ready = self._ready[-1], []
+        return newest
 
     def flush_all(self):
         from . import engine as E
-        if not self._fifo:
-            return []
-        E.welch_dist_flush()
-        return self._pop(len(self._fifo))
+        if _ENGINE_FIFO:
+            E.welch_dist_flush()
+            self._report(len(_ENGINE_FIFO))
+        done, self._ready = self._ready, []
+        return done
 
     def flush(self):
         done = self.flush_all()

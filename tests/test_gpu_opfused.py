@@ -14,7 +14,10 @@ from oracle import cpu_ref as O
 
 
 def _both(fn):
+    """(default: one-launch epilogue, and -- nfft 4096 on the pipeline kernel, COLA window -- the lobe sums from the back role
+    [k_welch_pipe mode 9, k_op_fused<LOBEB>];  SP_OP_UNFUSED=1: block sums + k_op_colsums + k_op_finish)"""
     os.environ.pop("SP_OP_UNFUSED", None)
+    os.environ.pop("SP_OP_NOLOBESUM", None)
     a = fn()
     os.environ["SP_OP_UNFUSED"] = "1"
     try:
@@ -22,6 +25,17 @@ def _both(fn):
     finally:
         os.environ.pop("SP_OP_UNFUSED", None)
     return a, b
+
+
+def _three(fn):
+    """default | one-launch epilogue on the block sums (SP_OP_NOLOBESUM=1) | two-launch form"""
+    a, c = _both(fn)
+    os.environ["SP_OP_NOLOBESUM"] = "1"
+    try:
+        b = fn()
+    finally:
+        os.environ.pop("SP_OP_NOLOBESUM", None)
+    return a, b, c
 
 
 @pytest.mark.parametrize("wname", ["Hanning", "Hamming", "Nuttall4", "SFT3F", "HFT70"])
@@ -104,3 +118,40 @@ def test_non_cosine_window_keeps_the_transform_form():
     assert np.array_equal(pf, pu)
     ref = O.welch_psd_stream(s, win, nfft, hop, M, 1.0, detrend_style=1) * np.sum(win ** 2)
     np.testing.assert_allclose(pf, ref, rtol=2e-4, atol=1e-6 * ref.max())
+
+
+@pytest.mark.parametrize("cplx", [True, False])
+@pytest.mark.parametrize("hop,M", [(2048, 9001), (1024, 8500), (2048, 8193)])
+def test_lobe_sums_from_the_back_role(cplx, hop, M):
+    """k_welch_pipe mode 9 + k_op_fused<LOBEB>: the lobe bins of sum_g X_g from the back role's registers and the samples' plain
+    sum from the DC bin through the window's COLA constant, edges corrected -- against the block-sum forms and the oracle.  The
+    mean is large and drifts, the record has a ragged end (samples beyond the last frame count in the mean)."""
+    from pyfft_amd import engine as E
+    rng = np.random.default_rng(hop + M)
+    nfft = 4096
+    n = (M - 1) * hop + nfft + 777
+    x = rng.standard_normal(n) + (1j * rng.standard_normal(n) if cplx else 0.0) + (7.0 - (2.0j if cplx else 0.0))
+    x[: n // 3] += 3.0
+    x = x.astype(np.complex64 if cplx else np.float32)
+    for wname in ("Hanning", "Hamming"):
+        win = O.windows(wname, nwins=nfft)
+        S2 = float(np.sum(win ** 2))
+        a, b, c = _three(lambda: E.welch_psd(x, win, hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0 / S2))
+        if cplx:
+            assert "lobesum" in E.profile_last_kernel() or True
+        assert np.max(np.abs(a - b)) <= 2e-6 * b.max() and np.max(np.abs(a - c)) <= 2e-6 * c.max(), wname
+        ref = O.welch_psd_stream(x, win, nfft, hop, M, 1.0, detrend_style=1)
+        np.testing.assert_allclose(a, ref, rtol=2e-4, atol=1e-6 * ref.max())
+    # the kernel really is the lobe-sum form for complex input (real input takes the two-frames-per-transform kernels)
+    E.welch_psd(x, O.windows("Hanning", nwins=nfft), hop, M, detrend=True, sided=E.SIDED_TWO, scale=1.0)
+    if cplx:
+        assert "lobesum" in E.profile_last_kernel(), E.profile_last_kernel()
+    # the sharded state: shards with different estimates and edges add up
+    if cplx:
+        win = O.windows("Hanning", nwins=nfft)
+        ref = O.welch_psd_stream(x, win, nfft, hop, M, 1.0, detrend_style=1) * np.sum(win ** 2)
+        f1 = M - 150                       # (the second shard is small: k_welch_carry and block sums there, lobe sums in the first)
+        sa = E.welch_export(x[: (f1 - 1) * hop + nfft], win, hop, f1, nmean=f1 * hop)
+        sb = E.welch_export(x[f1 * hop:], win, hop, M - f1, nmean=n - f1 * hop)
+        p = E.welch_apply(sa + sb, win, M, sided=E.SIDED_TWO, scale=1.0)
+        np.testing.assert_allclose(p, ref, rtol=2e-4, atol=1e-6 * ref.max())
