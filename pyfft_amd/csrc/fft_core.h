@@ -16,6 +16,7 @@
 // Twiddles W_N^m come from a per-N global table (float, rounded from double on the host) and
 // are held in registers across frames.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 namespace sp {
@@ -131,10 +132,15 @@ __device__ __forceinline__ void dft4s(cf &a, cf &b, cf &c, cf &d, float rb, floa
 // x (1 - i t)
 __device__ __forceinline__ cf rot_tan(cf a, float t) { return mk(fmaf(t, a.y, a.x), fmaf(-t, a.x, a.y)); }
 
-template <bool TWD> __device__ __forceinline__ void dft16s(cf (&x)[16], const Tw16 &w) {
+// PREROT: the inputs arrive already rotated by (1 - i tau_s) -- the producing pass applied the rotation to its outputs before the
+// exchange (wave-specialised pipeline: the rotations of pass p + 1 are work of role p); the pending scales g_s are absorbed here
+// as always
+template <bool TWD, bool PREROT = false> __device__ __forceinline__ void dft16s(cf (&x)[16], const Tw16 &w) {
     if constexpr (TWD) {
+        if constexpr (!PREROT) {
 #pragma unroll
-        for (int s = 1; s < 16; ++s) x[s] = rot_tan(x[s], w.f[Tw16::TAU + s - 1]);
+            for (int s = 1; s < 16; ++s) x[s] = rot_tan(x[s], w.f[Tw16::TAU + s - 1]);
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) dft4s(x[b], x[b + 4], x[b + 8], x[b + 12], w.f[Tw16::RB + b], w.f[Tw16::RC + b], w.f[Tw16::RD + b]);
     } else {
@@ -171,10 +177,12 @@ template <bool TWD> __device__ __forceinline__ void dft16s(cf (&x)[16], const Tw
 // butterfly: the 16 LDS stores of a Stockham scatter are then spread over the last 64 VALU instructions of the pass
 // instead of forming one burst behind it (SP_EARLY_SCATTER; the burst is where the waves queue on the LDS pipe:
 // SQ_WAIT_INST_LDS was 16 % of the wave cycles of the metric kernel).
-template <bool TWD, class Store> __device__ __forceinline__ void dft16s_es(cf (&x)[16], const Tw16 &w, Store store) {
+template <bool TWD, class Store, bool PREROT = false> __device__ __forceinline__ void dft16s_es(cf (&x)[16], const Tw16 &w, Store store) {
     if constexpr (TWD) {
+        if constexpr (!PREROT) {
 #pragma unroll
-        for (int s = 1; s < 16; ++s) x[s] = rot_tan(x[s], w.f[Tw16::TAU + s - 1]);
+            for (int s = 1; s < 16; ++s) x[s] = rot_tan(x[s], w.f[Tw16::TAU + s - 1]);
+        }
 #pragma unroll
         for (int b = 0; b < 4; ++b) dft4s(x[b], x[b + 4], x[b + 8], x[b + 12], w.f[Tw16::RB + b], w.f[Tw16::RC + b], w.f[Tw16::RD + b]);
     } else {
@@ -234,9 +242,23 @@ __device__ __forceinline__ void dft4w(cf &a, cf &b, cf &c, cf &d, float wa, floa
     b = mk(t1.x + t3.y, t1.y - t3.x);           // t1 - i t3
     d = mk(t1.x - t3.y, t1.y + t3.x);
 }
-template <class Store> __device__ __forceinline__ void dft16s_es_win(cf (&x)[16], const float (&w)[16], Store store) {
+struct NoMid {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// mid(b), b = 0..2: called behind the b-th first-stage butterfly, pinned there (the pipeline's front role issues its spread sample
+// loads at these points -- a quarter of a pass apart -- instead of behind the last stage's stores)
+template <class Store, class Mid = NoMid> __device__ __forceinline__ void dft16s_es_win(cf (&x)[16], const float (&w)[16], Store store, Mid mid = Mid()) {
 #pragma unroll
-    for (int b = 0; b < 4; ++b) dft4w(x[b], x[b + 4], x[b + 8], x[b + 12], w[b], w[b + 4], w[b + 8], w[b + 12]);
+    for (int b = 0; b < 4; ++b) {
+        dft4w(x[b], x[b + 4], x[b + 8], x[b + 12], w[b], w[b + 4], w[b + 8], w[b + 12]);
+        if constexpr (!std::is_same<Mid, NoMid>::value) {
+            if (b < 3) {
+                __builtin_amdgcn_sched_barrier(0);
+                mid(b);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
     x[5] = rot_tan(x[5], SP_T16);
     x[9] = mk(x[9].x + x[9].y, x[9].y - x[9].x);
     x[13] = rot_tan(x[13], SP_T316);
@@ -680,6 +702,45 @@ template <int N, bool TW1LDS = false, bool RM = false> struct WgFft {
         auto store = [&](int k, cf val) __attribute__((always_inline)) { lds[phys<P>(base + k * NS)] = val; };
         if constexpr (P > 0) dft16s_es<true>(v, t16[P - 1], store);
         else dft16s_es<false>(v, t16[0], store);
+    }
+
+    // tau_out[k], k = 0..15: the rotation (1 - i tau) that pass P + 1 applies to the element this thread's pass-P output k becomes
+    // (Stockham position p = (tid / NS) 16 NS + tid % NS + k NS -> consumer thread p % T, slot p / T; its twiddle is table[e s]
+    // with e = (thread % NS') (N / (16 NS')), NS' = 16 NS).  tau as make_tw16 forms it.
+    template <int P> __device__ __forceinline__ void load_tau_out(const cf *__restrict__ table, int tid, float (&tau)[16]) const {
+        static_assert(P + 1 < NP && PL::radix(P) == 16 && PL::radix(P + 1) == 16 && R == 16, "between two radix-16 passes");
+        constexpr int NS = PL::ns(P), NS2 = PL::ns(P + 1);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int p = (tid / NS) * (NS * 16) + (tid % NS) + k * NS;
+            const int tc = p % T, sc = p / T;
+            const int e = (tc % NS2) * (N / (NS2 * 16));
+            const cf w = table[(e * sc) & (N - 1)];
+            float c = w.x;
+            if (fabsf(c) < 9.094947e-13f) c = c < 0.f ? -9.094947e-13f : 9.094947e-13f;   // 2^-40, as make_tw16
+            tau[k] = sc == 0 ? 0.f : -w.y / c;
+        }
+    }
+    // butterflies of pass P on inputs that arrive pre-rotated (PREROT), outputs rotated for pass P + 1 and scattered
+    template <int P, bool PREROT> __device__ __forceinline__ void bfly_scatter_rot(cf (&v)[R], const float (&tau)[16], cf *lds, int tid) const {
+        constexpr int NS = PL::ns(P);
+        const int base = (tid / NS) * (NS * 16) + (tid % NS);
+        auto store = [&](int k, cf val) __attribute__((always_inline)) { lds[phys<P>(base + k * NS)] = rot_tan(val, tau[k]); };
+        if constexpr (P > 0) dft16s_es<true, decltype(store), PREROT>(v, t16[P - 1], store);
+        else dft16s_es<false>(v, t16[0], store);
+    }
+    __device__ __forceinline__ void bfly_scatter_win_rot(cf (&v)[R], const float (&w)[R], const float (&tau)[16], cf *lds, int tid) const {
+        static_assert(R == 16, "radix-16 first pass");
+        constexpr int NS = PL::ns(0);
+        const int base = (tid / NS) * (NS * 16) + (tid % NS);
+        auto store = [&](int k, cf val) __attribute__((always_inline)) { lds[phys<0>(base + k * NS)] = rot_tan(val, tau[k]); };
+        dft16s_es_win(v, w, store);
+    }
+    // butterflies of the LAST pass P on pre-rotated inputs (registers only)
+    template <int P> __device__ __forceinline__ void bfly_prerot(cf (&v)[R], int tid) const {
+        (void)tid;
+        static_assert(P > 0 && PL::radix(P) == 16 && R == 16, "a twiddled radix-16 pass");
+        dft16s<true, true>(v, t16[P - 1]);
     }
 
     // pass 0 on RAW samples with the window folded into the first radix-4 stage (dft16s_es_win), scatter folded in

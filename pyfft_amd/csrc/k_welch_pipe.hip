@@ -43,6 +43,19 @@
 #ifndef SP_PIPE_WINFOLD
 #define SP_PIPE_WINFOLD 1
 #endif
+// SP_PIPE_EARLYSPREAD=1 (with the window fold): the three later groups of the front role's spread loads leave behind the first-stage
+// butterflies instead of behind the last stage's stores: in flight longer before their use -- but bunched into the first third of
+// the period, and measured SLOWER (bench step 0.570 against 0.555 ms, three interleaved warm rounds, profiles/r03_pipe_ab.txt):
+// what the loads need is even spacing (the CU's miss queue), not more lead (three frames ahead is no faster either).  Default off.
+#ifndef SP_PIPE_EARLYSPREAD
+#define SP_PIPE_EARLYSPREAD 0
+#endif
+// SP_PIPE_UPROT=1: the input rotations (1 - i tau) of pass p + 1 are applied by role p to its outputs before the scatter: 30 VALU
+// move from the back role (the longest: 206 VALU + its gather) to the front role (which has slack since the window fold and
+// the lobe sums), the middle role's count stays (it gives 30 and takes 30)
+#ifndef SP_PIPE_UPROT
+#define SP_PIPE_UPROT 1
+#endif
 #ifndef SP_PIPE_RM
 #define SP_PIPE_RM 0          // 1: first exchange image [thread][16] (fft_core.h, WgFft RM): 16-byte scatter writes
 #endif
@@ -157,6 +170,13 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
     constexpr int DRAIN = 4;                 // a frame leaves the pipeline 4 periods after it entered
     const int64_t periods = trips + DRAIN;
     F f;
+    // (not for the real-pair fronts: three rotating register sets + window leave no room for 16 more constants -- 12-37 spills)
+    constexpr bool UPROT = SP_PIPE_UPROT && !RP && !SP_PIPE_RM && !SP_ABLATE && SP_PIPE_ES;
+    float tau_out[16];                       // UPROT: rotations this role applies to its outputs (front: for pass 1, middle: for pass 2)
+    if constexpr (UPROT) {
+        if (role == 0) f.template load_tau_out<0>(tb.tw, tid, tau_out);
+        else if (role == 1) f.template load_tau_out<1>(tb.tw, tid, tau_out);
+    }
 
     if (role == 0 && RP) {
         // real input, frames 2q and 2q + 1 in one transform: z = f_2q + i f_2q+1 (the finish kernel symmetrises |Z|^2).  At hop
@@ -202,11 +222,13 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             if constexpr (SP_PIPE_WINFOLD && !SP_PIPE_RM && !SP_ABLATE) {
 #pragma unroll
                 for (int t = 0; t < R; ++t) v[t] = mk(cur[t], HB ? (t < R / 2 ? cur[t + R / 2] : nxt[t - R / 2]) : 0.f);
-                f.bfly_scatter_win(v, w, img, tid);
+                if constexpr (UPROT) f.bfly_scatter_win_rot(v, w, tau_out, img, tid);
+                else f.bfly_scatter_win(v, w, img, tid);
             } else {
 #pragma unroll
                 for (int t = 0; t < R; ++t) v[t] = mk(w[t] * cur[t], HB ? w[t] * (t < R / 2 ? cur[t + R / 2] : nxt[t - R / 2]) : 0.f);
-                f.template bfly_scatter<0>(v, img, tid);
+                if constexpr (UPROT) f.template bfly_scatter_rot<0, false>(v, tau_out, img, tid);
+                else f.template bfly_scatter<0>(v, img, tid);
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (ONEPASS) {
@@ -330,16 +352,21 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             // 16 KiB at the top of a period blocks at issue (350 cycles per period measured) while the same loads spread
             // over the period find the queue drained
             {
+                constexpr bool EARLY = SP_PIPE_EARLYSPREAD && WINFOLD;
                 auto store = [&](int k, cf val) __attribute__((always_inline)) {
-                    img[F::template phys<0>(tid * 16 + k)] = val;
-                    if (k >= 12 && k < 15) issue_part(fill, i + AHEAD, (k - 11) * (SHIFT / 4), (k - 10) * (SHIFT / 4));
+                    img[F::template phys<0>(tid * 16 + k)] = UPROT ? rot_tan(val, tau_out[k]) : val;
+                    if constexpr (!EARLY)
+                        if (k >= 12 && k < 15) issue_part(fill, i + AHEAD, (k - 11) * (SHIFT / 4), (k - 10) * (SHIFT / 4));
                 };
-                if constexpr (WINFOLD) dft16s_es_win(v, w, store);
+                auto mid = [&](int b) __attribute__((always_inline)) { issue_part(fill, i + AHEAD, (b + 1) * (SHIFT / 4), (b + 2) * (SHIFT / 4)); };
+                if constexpr (EARLY) dft16s_es_win(v, w, store, mid);
+                else if constexpr (WINFOLD) dft16s_es_win(v, w, store);
                 else dft16s_es<false>(v, f.t16[0], store);
             }
             } else {
 #if SP_PIPE_ES && !SP_ABLATE
-            f.template bfly_scatter<0>(v, img, tid);
+            if constexpr (UPROT) f.template bfly_scatter_rot<0, false>(v, tau_out, img, tid);
+            else f.template bfly_scatter<0>(v, img, tid);
 #else
             f.template bfly<0>(v, tid);
             if constexpr (!(SP_ABLATE & 2)) f.template scatter<0>(v, img, tid);
@@ -362,21 +389,15 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             cf s0[SHIFT], s1[SHIFT], s2[SHIFT];
             issue(s1, 1);
             issue(s2, 2);
-            for (; i + 5 < trips; i += 6) {
-                frame(i, imgA, s0, s1);
+            for (; i + 2 < trips; i += 3) {            // (image by parity of the period: a scalar select, so that the loop unrolls by 3 only)
+                frame(i, (i & 1) ? imgA + IMG : imgA, s0, s1);
                 PIPE_SYNC();
-                frame(i + 1, imgA + IMG, s1, s2);
+                frame(i + 1, ((i + 1) & 1) ? imgA + IMG : imgA, s1, s2);
                 PIPE_SYNC();
-                frame(i + 2, imgA, s2, s0);
-                PIPE_SYNC();
-                frame(i + 3, imgA + IMG, s0, s1);
-                PIPE_SYNC();
-                frame(i + 4, imgA, s1, s2);
-                PIPE_SYNC();
-                frame(i + 5, imgA + IMG, s2, s0);
+                frame(i + 2, ((i + 2) & 1) ? imgA + IMG : imgA, s2, s0);
                 PIPE_SYNC();
             }
-            for (; i < trips; ++i) {                   // i is a multiple of 6 at entry of this tail: rotation state i % 3
+            for (; i < trips; ++i) {                   // i is a multiple of 3 at entry of this tail: rotation state i % 3
                 cf *img = (i & 1) ? imgA + IMG : imgA;
                 if (i % 3 == 0) frame(i, img, s0, s1);
                 else if (i % 3 == 1) frame(i, img, s1, s2);
@@ -431,7 +452,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             }
             if (p >= 2 && p <= trips + 1) {
 #if SP_PIPE_ES && !SP_ABLATE
-                f.template bfly_scatter<1>(use, dst, tid);
+                if constexpr (UPROT) f.template bfly_scatter_rot<1, true>(use, tau_out, dst, tid);
+                else f.template bfly_scatter<1>(use, dst, tid);
 #else
                 f.template bfly<1>(use, tid);
                 if constexpr (!(SP_ABLATE & 2)) f.template scatter<1>(use, dst, tid);
@@ -474,7 +496,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
                 }
             }
             if (p >= 4 && p <= trips + 3) {
-                f.template bfly<2>(use, tid);
+                if constexpr (UPROT) f.template bfly_prerot<2>(use, tid);
+                else f.template bfly<2>(use, tid);
                 if constexpr (SPEC) {
                     const int64_t pr = g0 + (p - 4);                         // global pair index (uniform); runs start even
                     const bool lone = (pr & 1) == 0 && p == trips + 3;       // a last even pair without a partner

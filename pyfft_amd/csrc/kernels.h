@@ -2046,7 +2046,9 @@ struct OpPrev {                 // the previous step of the pipelined sharded PS
 // (k_welch_pipe: 3 waves of 136 VGPRs per SIMD, 128.5 of 160 KiB LDS) leaves 104 VGPRs per SIMD and plenty of wave slots, so a
 // workgroup of 256 threads (one wave per SIMD) with <= 104 VGPRs fits next to it (the 512-thread form with 190 does not: its
 // workgroups waited for the main kernel to drain and the overlap was lost, profiles/r03_stream_overlap.txt).  Two bins per thread
-// and chunk: more round trips for the last block, which nobody waits for.
+// and chunk: more round trips for the last block, which nobody waits for.  (Since the rotations moved one role upstream the
+// main kernel allocates 144 VGPRs per wave, 80 are left per SIMD: the light form is held to 80 -- waves_per_eu 6 -- and spills
+// a few registers in its last block, whose latency nobody sees.)
 #define SP_OPF_WG 512
 #define SP_OPF_WG_LIGHT 256
 // LOBEB: the main kernel ran in mode 9 (k_welch_pipe): no block sums -- m1 is lobeB[G][8], the groups' sums of the spectra at the
@@ -2057,7 +2059,7 @@ struct OpPrev {                 // the previous step of the pipelined sharded PS
 // no c[n] rebuild (the last block's big round trip).
 template <bool CPLX, bool EXPORT, int E, bool LIGHT = false, bool LOBEB = false>
 static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
-    __attribute__((amdgpu_waves_per_eu(LIGHT ? 5 : 2, LIGHT ? 8 : 2))) void k_op_fused(const float *__restrict__ m0, int N, double *__restrict__ Acol,
+    __attribute__((amdgpu_waves_per_eu(LIGHT ? 6 : 2, LIGHT ? 8 : 2))) void k_op_fused(const float *__restrict__ m0, int N, double *__restrict__ Acol,
                                                                 const float *__restrict__ m1, int H, double *__restrict__ Sl,
                                                                 int64_t G, unsigned *__restrict__ ticket,
                                                                 const void *__restrict__ x, const float *__restrict__ trend,
