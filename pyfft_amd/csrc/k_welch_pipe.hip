@@ -219,7 +219,8 @@ __global__ __launch_bounds__(768) void k_welch_pipe(const void *__restrict__ x_i
             issue_chunk(fill, g0 + i + 2);
             __builtin_amdgcn_sched_barrier(0);
             cf v[R];
-            if constexpr (SP_PIPE_WINFOLD && !SP_PIPE_RM && !SP_ABLATE) {
+            // (not with the one-pass block sums: modes 4 / 7 then spill 17-20 registers instead of 2-6)
+            if constexpr (SP_PIPE_WINFOLD && !ONEPASS && !SP_PIPE_RM && !SP_ABLATE) {
 #pragma unroll
                 for (int t = 0; t < R; ++t) v[t] = mk(cur[t], HB ? (t < R / 2 ? cur[t + R / 2] : nxt[t - R / 2]) : 0.f);
                 if constexpr (UPROT) f.bfly_scatter_win_rot(v, w, tau_out, img, tid);
