@@ -76,6 +76,46 @@ int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B
     return 0;
 }
 
+int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, BigTw btN) {
+    if (xc.blue || A < 2 || B < 2) return -1;
+    const int64_t nslots = A * B / 2 + 1;
+#define RM_(LL)                                                                                        \
+    case LL: {                                                                                        \
+        constexpr int HP = WgCfg<LL>::FPW / 2;                                                        \
+        const int64_t iters = (nslots + HP - 1) / HP, cap = (int64_t)c.ncu * 4;                       \
+        hipLaunchKernelGGL((k_hilbert_rowsmid<LL>), dim3((unsigned)(iters < cap ? iters : cap)), dim3(WgCfg<LL>::WG),   \
+                           WgCfg<LL>::lds_bytes(1), c.stream, Tm, A, B, xc.tb, btN);                  \
+        return 0;                                                                                     \
+    }
+    switch (xc.L) {
+        RM_(32) RM_(64) RM_(128) RM_(256) RM_(512) RM_(1024) RM_(2048)
+        default: return -1;
+    }
+#undef RM_
+}
+
+int launch_fft_cols_inv(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
+                        const Xf &xf, BigTw bt, float scale, const RowsOut *analytic) {
+    if (xf.blue) return -1;
+    const int fpw = fpw_of(xf.L);
+    if (ncols % fpw || nouter < 1) return -1;
+    const int64_t ncb = ncols / fpw, total = ncb * nouter, cap = (int64_t)c.ncu * 6;
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
+    const RowsOut ro = analytic ? *analytic : RowsOut{nullptr, 0, 0, nullptr};
+#define CI_(LL)                                                                                        \
+    case LL:                                                                                          \
+        if (analytic) hipLaunchKernelGGL((k_fft_cols_inv<LL, 2>), dim3(grid), dim3(WgCfg<LL>::WG), WgCfg<LL>::lds_bytes(1), c.stream, in, out, \
+                                         ncb, nouter, es, os, twmul, xf.tb, bt, scale, ro);           \
+        else hipLaunchKernelGGL((k_fft_cols_inv<LL, 0>), dim3(grid), dim3(WgCfg<LL>::WG), WgCfg<LL>::lds_bytes(1), c.stream, in, out, ncb, \
+                                nouter, es, os, twmul, xf.tb, bt, scale, ro);                         \
+        return 0;
+    switch (xf.L) {
+        CI_(64) CI_(128) CI_(256)
+        default: return -1;
+    }
+#undef CI_
+}
+
 int launch_hilbert_mid(LaunchCtx c, cf *Z, int64_t M, BigTw bt) {
     const int64_t n = M / 2 + 1;
     const int64_t cap = (int64_t)c.ncu * 16;

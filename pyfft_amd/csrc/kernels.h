@@ -572,6 +572,143 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restr
     }
 }
 
+// ---- half-length Hilbert of a long real row with the middle step inside a ROW pass (round 3) -----------------------------------
+// The forward three-pass transform ends with contiguous rows (ka, kb) of C points, and the transform can be inverted by the
+// adjoint passes in REVERSED order, which starts with the same rows.  The middle step couples bin k with M - k: for k = ka + A
+// (kb + B kc) the partner is row (A - ka, B - 1 - kb), element C - 1 - kc (ka != 0); row (0, B - kb), element C - 1 - kc (ka = 0,
+// kb != 0); row (0, 0) itself, element C - kc.  So a workgroup that owns a row AND its mirror row can run
+//   forward row FFT -> k_hilbert_mid's arithmetic on (k, M - k) through one LDS exchange -> inverse row FFT
+// in place: the forward's last pass store, the middle step's load + store and the inverse's first pass load never touch HBM
+// (4 x 64 MB of the 960 MB a 2^24-sample Hilbert moved; 7 launches -> 5).  k_fft_cols_inv are the two adjoint column passes:
+// the inter-pass twiddle (conjugate) BEFORE the transform; the last one writes the analytic signal.
+template <int L>
+__global__ __launch_bounds__(WgCfg<L>::WG) void k_hilbert_rowsmid(cf *__restrict__ Tm, int64_t A, int64_t B, XfTables tb, BigTw btN) {
+    using X = XfPow2<L>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
+    static_assert(C::FPW >= 2 && (C::FPW % 2) == 0, "a workgroup holds rows and their mirror rows");
+    constexpr int HP = C::FPW / 2;                               // row pairs per workgroup and iteration
+    const int64_t AB = A * B, nslots = AB / 2 + 1;               // pairs + the two self-mirrored rows (0, 0), (0, B/2)
+    const int side = grp >= HP ? 1 : 0;
+    const int pg = side ? grp - HP : grp;
+    auto look = [&](int64_t m) __attribute__((always_inline)) { return cmul(btN.hi[m >> btN.lb], btN.lo[m & ((1 << btN.lb) - 1)]); };
+    for (int64_t s0 = (int64_t)blockIdx.x * HP; s0 < nslots; s0 += (int64_t)gridDim.x * HP) {
+        const int64_t s = s0 + pg;
+        const bool slot_ok = s < nslots;
+        const int64_t sc = slot_ok ? s : 0;
+        int64_t ka, kb;
+        bool self = false;
+        if (sc < AB / 2 - B) {                                   // rows with 1 <= ka < A/2 (mirror: A/2 < ka' <= A - 1)
+            const int64_t j = B + sc;
+            ka = j / B;
+            kb = j % B;
+        } else {
+            const int64_t s2 = sc - (AB / 2 - B);
+            if (s2 < B / 2 - 1) {                                // (0, kb), 1 <= kb < B/2  <->  (0, B - kb)
+                ka = 0;
+                kb = 1 + s2;
+            } else if (s2 < B - 1) {                             // (A/2, kb), kb < B/2  <->  (A/2, B - 1 - kb)
+                ka = A / 2;
+                kb = s2 - (B / 2 - 1);
+            } else {                                             // the two rows that are their own mirror
+                ka = 0;
+                kb = s2 == B - 1 ? 0 : B / 2;
+                self = true;
+            }
+        }
+        const int64_t kam = ka != 0 ? A - ka : 0, kbm = ka != 0 ? B - 1 - kb : (B - kb) % B;
+        const int64_t myka = side ? kam : ka, mykb = side ? kbm : kb;
+        const bool act = slot_ok && !(self && side);
+        cf *row = Tm + (myka * B + mykb) * (int64_t)L;
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = row[tid + C::T * t];
+        xf.fwd(v, lds, tid, L);
+        __syncthreads();                                         // every group is done with its transform image
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) lds[tid + C::T * t] = v[t];
+        __syncthreads();
+        const cf *pl = smem + (self ? grp : (side ? grp - HP : grp + HP)) * C::LDS_PER;
+        const bool zero_row = myka == 0 && mykb == 0;
+        cf b[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int kc = tid + C::T * t;
+            b[t] = pl[zero_row ? ((L - kc) & (L - 1)) : (L - 1 - kc)];
+        }
+        __syncthreads();                                         // the images are free for the next transform
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int64_t k = myka + A * (mykb + B * (int64_t)(tid + C::T * t));
+            const cf w = look(k);                                // W_N^k, N = 2 M
+            const cf a = v[t], bb = b[t];
+            const cf p = mk(a.x + bb.x, a.y - bb.y), q = mk(a.x - bb.x, a.y + bb.y);          // a + conj b, a - conj b
+            const cf r = cmul(cconj(w), p) - cmul(w, q);
+            v[t] = k == 0 ? mk(0.f, 0.f) : mk(0.5f * r.x, -0.5f * r.y);                       // conj(Z'[k]): inverse = conj(fft(conj))
+        }
+        xf.fwd(v, lds, tid, L);
+        if (act) {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) row[tid + C::T * t] = mk(v[t].x, -v[t].y);
+        }
+        __syncthreads();
+    }
+}
+
+// adjoint of k_fft_cols for the reversed-order inverse: out[i] = sum_k conj(W_N^{mc k}) in[k] W_L^{-i k} (unscaled) as
+// conj(fft(W_N^{mc k} conj(in[k]))).  OUT 0: complex, in place or not; OUT 2: the LAST pass of the half-length Hilbert -- element
+// index j = base + i es is the sample-pair index, written is the analytic signal a[2j] = rx[2j] + i scale Re, a[2j+1] = rx[2j+1] + i
+// scale Im (RowsOut kind 2's output, 16 adjacent columns = 256 contiguous bytes per row).
+template <int L, int OUT>
+__global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fft_cols_inv(
+    const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
+    XfTables tb, BigTw bt, float scale, RowsOut ro) {
+    using X = XfPow2<L>;
+    using C = typename X::C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *smem = reinterpret_cast<cf *>(smem_raw);
+    const int grp = C::FPW == 1 ? 0 : (int)threadIdx.x % C::FPW;
+    const int tid = C::FPW == 1 ? (int)threadIdx.x : (int)threadIdx.x / C::FPW;
+    cf *lds = smem + grp * C::LDS_PER;
+    X xf;
+    xf.init(tb, tid);
+    const int64_t total = nouter * ncolblocks;
+    for (int64_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+        const int64_t col = (idx % ncolblocks) * C::FPW + grp;
+        const int64_t base = (idx / ncolblocks) * os + col;
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const cf a = in[base + (int64_t)(tid + C::T * t) * es];
+            v[t] = mk(a.x, -a.y);
+        }
+        const int64_t mc = twmul * col;
+        if constexpr (C::R == 16) {
+            bigtw_apply16(v, bt, mc * (int64_t)tid, mc * (int64_t)C::T);
+        } else {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t m = mc * (int64_t)(tid + C::T * t);
+                v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
+            }
+        }
+        xf.fwd(v, lds, tid, L);
+        if constexpr (OUT == 2) {
+            float4 *ao = reinterpret_cast<float4 *>(ro.co);
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t j = base + (int64_t)(tid + C::T * t) * es;
+                const bool ok0 = 2 * j < ro.n, ok1 = 2 * j + 1 < ro.n;
+                const float x0 = ro.rx[ok0 ? 2 * j : 0], x1 = ro.rx[ok1 ? 2 * j + 1 : 0];
+                ao[j] = make_float4(ok0 ? x0 : 0.f, scale * v[t].x, ok1 ? x1 : 0.f, -scale * v[t].y);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) out[base + (int64_t)(tid + C::T * t) * es] = mk(scale * v[t].x, -scale * v[t].y);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // A3+A4  fused Welch PSD (fft_analysis.py:2156-2176 loop + :1946 |X|^2 + :1980 mean), generic form.
 // Each group owns frames [gid*fpg, (gid+1)*fpg); |X|^2 is accumulated in registers over the

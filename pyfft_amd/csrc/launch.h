@@ -187,6 +187,10 @@ int launch_cog_finish_op(LaunchCtx c, const cf *acc, int wpf, int64_t nframes, d
                          const double *st, const float *trend, int64_t nmean, int n);
 int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld = 0);
 int launch_hilbert_mid(LaunchCtx c, cf *Z, int64_t M, BigTw bt);
+// half-length Hilbert with the middle step inside the row pass + the two adjoint column passes (k_hilbert_rowsmid, k_fft_cols_inv)
+int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, BigTw btN);
+int launch_fft_cols_inv(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
+                        const Xf &xf, BigTw bt, float scale, const RowsOut *analytic);
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out,
                    const cf *H = nullptr);
 int launch_spec_mul(LaunchCtx c, cf *X, const cf *H, int64_t n);

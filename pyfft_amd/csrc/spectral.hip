@@ -2168,6 +2168,36 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
                 BigFuse fz;
                 const float *row = xd + b * x_ld;
                 fz.ci = ColsIn{3, row, (((uintptr_t)row) & 7) == 0 ? row : nullptr, nullptr, nuse};      // r2 == r1: aligned pairs
+                if (!env_flag("SP_HILBERT_NOFUSEMID")) {
+                    // round 3: the middle step inside a row pass that owns mirror row pairs, the inverse as the adjoint passes in
+                    // reversed order (k_hilbert_rowsmid, k_fft_cols_inv): 5 launches, 768 MB at 2^24 samples instead of 7 / 960
+                    int lg = 0;
+                    while (((int64_t)1 << lg) < Mh) ++lg;
+                    int la_ = (lg + 2) / 3;
+                    if (la_ > 8) la_ = 8;
+                    int lb_ = (lg - la_ + 1) / 2;
+                    if (lb_ > 8) lb_ = 8;
+                    const int lc_ = lg - la_ - lb_;
+                    const int64_t Aa = (int64_t)1 << la_, Bb = (int64_t)1 << lb_, Cc = (int64_t)1 << lc_;
+                    Xf xa, xb, xc;
+                    BigTw btM;
+                    if (get_xf(Aa, &xa) || get_xf(Bb, &xb) || get_xf(Cc, &xc) || get_bigtw(Mh, &btM)) return -1;
+                    if (Aa >= 64 && Bb >= 64 && Cc >= 32 && Cc <= 2048) {
+                        LAUNCHCHK(launch_fft_cols(lc(), A, A, Bb * Cc, 1, Bb * Cc, 0, 1, 0, xa, btM, 0, fz.ci));
+                        LAUNCHCHK(launch_fft_cols(lc(), A, A, Cc, Aa, Cc, Bb * Cc, Aa, 0, xb, btM));
+                        LAUNCHCHK(launch_hilbert_rowsmid(lc(), A, Aa, Bb, xc, btN));
+                        LAUNCHCHK(launch_fft_cols_inv(lc(), A, A, Cc, Aa, Cc, Bb * Cc, Aa, xb, btM, 1.f, nullptr));
+                        RowsOut ao;
+                        ao.co = reinterpret_cast<float *>(od + b * nfft);
+                        ao.n = nuse;
+                        ao.Ltot = nfft;
+                        ao.mom = nullptr;
+                        ao.rx = row;
+                        ao.kind = 2;
+                        LAUNCHCHK(launch_fft_cols_inv(lc(), A, nullptr, Bb * Cc, 1, Bb * Cc, 0, 1, xa, btM, (float)(1.0 / (double)Mh), &ao));
+                        continue;
+                    }
+                }
                 if (dev_fft_big_pow2(A, A, Mh, 0, 0, 1, &fz)) return -1;
                 LAUNCHCHK(launch_hilbert_mid(lc(), A, Mh, btN));
                 BigFuse fo;
@@ -2312,8 +2342,9 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
     if (get_trendbuf(3, &tb)) return -1;
     double *scr = moments_scratch();
     if (!scr) return -1;
-    LAUNCHCHK(launch_moments(lc(), a, false, n, 1, scr, tb.d, nullptr));
-    LAUNCHCHK(launch_moments(lc(), b, false, n, 1, scr, tb.d + 8, nullptr));
+    // both signals' mean / variance in ONE pair of launches (two "channels" b - a samples apart: any two device rows; each
+    // signal's own pass cost 21 + 8 us of the long ccf's 0.9 ms)
+    LAUNCHCHK(launch_moments(lc(), a, false, n, 1, scr, tb.d, nullptr, 2, (int64_t)(b - a)));
     hipLaunchKernelGGL(k_xcorr_norm, dim3(1), dim3(64), 0, g.stream, tb.d, tb.d + 8, n, tb.d + 16);
     if (L <= SP_MAX_WG_FFT) {
         Xf xf;

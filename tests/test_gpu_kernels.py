@@ -716,6 +716,37 @@ def test_hilbert_long_half_length(E):
     assert np.max(np.abs(z - ref)) <= 2e-5 * np.abs(ref).max()
 
 
+@pytest.mark.parametrize("log2n", [21, 22, 23, 24, 25])
+def test_hilbert_long_middle_step_in_the_row_pass(E, log2n):
+    """round 3: forward row FFT -> the (k, M - k) middle step through one LDS exchange -> inverse row FFT in ONE kernel that
+    owns mirror row pairs, the inverse as the adjoint column passes in reversed order (k_hilbert_rowsmid, k_fft_cols_inv).
+    Every three-pass split (A, B, C) from 2^20 to 2^24 complex points; against the separate-middle-step form
+    (SP_HILBERT_NOFUSEMID=1) everywhere and the float64 oracle (hilbert.py:54-67) where that is quick."""
+    import os
+    rng = np.random.default_rng(log2n)
+    n = 1 << log2n
+    u = (rng.standard_normal(n) + 0.7).astype(np.float32)
+    z = E.hilbert_rows(u[None, :], n)[0]
+    os.environ["SP_HILBERT_NOFUSEMID"] = "1"
+    try:
+        z0 = E.hilbert_rows(u[None, :], n)[0]
+    finally:
+        del os.environ["SP_HILBERT_NOFUSEMID"]
+    assert np.max(np.abs(z - z0)) <= 5e-6 * np.abs(z0).max()
+    assert np.array_equal(z.real, u)                                  # the real part is the input itself
+    if log2n <= 23:
+        ref = O.hilbert(u.astype(np.float64))
+        assert np.max(np.abs(z - ref)) <= 2e-5 * np.abs(ref).max()
+    nuse = n - 12345                                                  # truncated / zero-padded row
+    z = E.hilbert_rows(u[None, :nuse], n)[0]
+    os.environ["SP_HILBERT_NOFUSEMID"] = "1"
+    try:
+        z0 = E.hilbert_rows(u[None, :nuse], n)[0]
+    finally:
+        del os.environ["SP_HILBERT_NOFUSEMID"]
+    assert np.max(np.abs(z - z0)) <= 5e-6 * np.abs(z0).max()
+
+
 # ---------------------------------------------------------------- A11 ccf
 def test_xcorr_golden(E):
     g = load_golden("ccf")
