@@ -30,7 +30,7 @@ int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_
 
 // three-pass long transform pieces (power-of-two lengths; ncols is a multiple of the columns per workgroup)
 int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
-                    int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n, ColsIn ci) {
+                    int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n, ColsIn ci, int tw_outer) {
     if (xf.blue) return -1;
     const int fpw = fpw_of(xf.L);
     if (ncols % fpw || nouter < 1) return -1;
@@ -40,13 +40,13 @@ int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t n
     const unsigned grid = (unsigned)(total < cap ? total : cap);
 #define M_(XT)                                                                                        \
     if (ci.kind == 1) hipLaunchKernelGGL((k_fft_cols<XT::L, 1>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, \
-                                         ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);                 \
+                                         ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer);       \
     else if (ci.kind == 3) hipLaunchKernelGGL((k_fft_cols<XT::L, 3>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, \
-                                              out, ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);       \
+                                              out, ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer); \
     else if (hmask_n > 0) hipLaunchKernelGGL((k_fft_cols<XT::L, 0, true>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, \
-                                             in, out, ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);           \
+                                             in, out, ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer); \
     else hipLaunchKernelGGL((k_fft_cols<XT::L, 0>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, ncb, nouter, \
-                            es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci);
+                            es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer);
     SP_DISPATCH_P(xf, M_)
 #undef M_
     return 0;
@@ -92,6 +92,43 @@ int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &
         default: return -1;
     }
 #undef RM_
+}
+
+int launch_xc_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, const Xf &xc2, BigTw btL, BigTw btM) {
+    if (xc.blue || xc2.blue || xc2.L * 2 != xc.L || A < 2 || B < 2) return -1;
+    const int64_t nslots = A * B / 2 + 1;
+#define XR_(LL)                                                                                        \
+    case LL: {                                                                                        \
+        constexpr int HP = WgCfg<LL>::FPW / 2;                                                        \
+        const int64_t iters = (nslots + HP - 1) / HP, cap = (int64_t)c.ncu * 4;                       \
+        const size_t lds = sizeof(cf) * (size_t)WgCfg<LL>::FPW * (LL + 32);                          \
+        hipLaunchKernelGGL((k_xc_rowsmid<LL>), dim3((unsigned)(iters < cap ? iters : cap)), dim3(WgCfg<LL>::WG), lds, c.stream, Tm, A, B, \
+                           xc.tb, xc2.tb, btL, btM);                                                  \
+        return 0;                                                                                     \
+    }
+    switch (xc.L) {
+        XR_(64) XR_(128) XR_(256) XR_(512) XR_(1024) XR_(2048)
+        default: return -1;
+    }
+#undef XR_
+}
+
+int launch_fft_cols_lag(LaunchCtx c, const cf *in, int64_t ncols, int64_t nouter, int64_t es, int64_t os, const Xf &xf, RowsOut ro) {
+    if (xf.blue) return -1;
+    const int fpw = fpw_of(xf.L);
+    if (ncols % fpw || nouter < 1) return -1;
+    const int64_t ncb = ncols / fpw, total = ncb * nouter, cap = (int64_t)c.ncu * 6;
+    const unsigned grid = (unsigned)(total < cap ? total : cap);
+#define CL_(LL)                                                                                        \
+    case LL:                                                                                          \
+        hipLaunchKernelGGL((k_fft_cols_lag<LL>), dim3(grid), dim3(WgCfg<LL>::WG), WgCfg<LL>::lds_bytes(1), c.stream, in, ncb, nouter, es, os, \
+                           xf.tb, ro);                                                                \
+        return 0;
+    switch (xf.L) {
+        CL_(64) CL_(128) CL_(256)
+        default: return -1;
+    }
+#undef CL_
 }
 
 int launch_fft_cols_inv(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,

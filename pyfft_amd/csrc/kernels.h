@@ -413,7 +413,7 @@ __global__ __launch_bounds__(WgCfg<L>::WG)
     __attribute__((amdgpu_waves_per_eu((KIND == 0 && !HM && L <= 256) ? SP_COLS_WAVES : 2,
                                        (KIND == 0 && !HM && L <= 256) ? SP_COLS_WAVES : 2))) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
                                                             int64_t nouter, int64_t es, int64_t os, int64_t twmul, int conj_in,
-                                                            XfTables tb, BigTw bt, int64_t hmask_n, ColsIn ci) {
+                                                            XfTables tb, BigTw bt, int64_t hmask_n, ColsIn ci, int tw_outer = 0) {
     using X = XfPow2<L>;
     using C = typename X::C;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -480,7 +480,9 @@ __global__ __launch_bounds__(WgCfg<L>::WG)
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, si * v[t].y);
         xf.fwd(v, lds, tid, L);
-        const int64_t mc = twmul * col;
+        // (tw_outer: the twiddle is indexed by the OUTER index instead of the column -- the ccf's half rows [ka][kb][ka'], where
+        //  the M-point transform's column index c' = ka is the outer one of the pass over kb)
+        const int64_t mc = twmul * (tw_outer ? idx / ncolblocks : col);
 #if SP_BIGTW_REC
         if constexpr (C::R == 16) {
             // W^{mc (tid + T t)} = W^{mc tid} (W^{mc T})^t: two table look-ups per thread instead of sixteen (each look-up is
@@ -652,6 +654,161 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_hilbert_rowsmid(cf *__restrict
             for (int t = 0; t < C::R; ++t) row[tid + C::T * t] = mk(v[t].x, -v[t].y);
         }
         __syncthreads();
+    }
+}
+
+// ---- long ccf: the forward transform's last (row) pass, k_xc_mid_half and the FIRST pass of the half-length transform in one kernel
+// Z = FFT_L(x1 + i x2) after its two column passes lies as rows (ka, kb) of C points.  The half-length spectrum Zp[k], k < M = L/2,
+// needs Z[k], Z[M + k] (same row: kc + C/2), Z[L - k] and Z[M - k] (the mirror row of k_hilbert_rowsmid, elements C - 1 - kc and
+// C/2 - 1 - kc): a workgroup that owns a row and its mirror row forms the C/2 values of Zp that belong to each.  And those values,
+// k = ka + A kb + A B kc, are exactly the input of the M-point transform under the split (A' = C/2, B' = B, C' = A) with a' = kc:
+// its first pass is the (C/2)-point transform along the row it already holds.  So: FFT_C -> middle step (one LDS exchange) ->
+// FFT_{C/2} -> the inter-pass twiddle W_M^{(kb A + ka) ka'} -> half rows [ka][kb][ka'] in place (row pitch C); two column passes follow (over
+// kb with the twiddle indexed by the OUTER index ka, then over ka), the last one writing the lags.  1.9 GB instead of 3.0 GB at
+// 2^24 samples, 5 launches instead of 7.
+template <int L>
+__global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm, int64_t A, int64_t B, XfTables tb, XfTables tb2,
+                                                            BigTw btL, BigTw btM) {
+    using X = XfPow2<L>;
+    SP_KERNEL_PROLOGUE(X)
+    (void)n;
+    static_assert(C::FPW >= 2 && (C::FPW % 2) == 0 && L >= 64, "a workgroup holds rows and their mirror rows");
+    constexpr int HP = C::FPW / 2, L2 = L / 2, T2 = C::T / 2;
+    using F2 = WgFft<L2>;
+    static_assert(F2::T == T2 && F2::R == C::R, "the half-length transform takes half the row's threads");
+    F2 f2;
+    const int tid2 = tid % T2, half = tid / T2;
+    f2.load_twiddles(tb2.tw, tid2);
+    // a group's LDS region here: L + 32 elements (the launcher sizes the allocation): the C-point image (L + 16) or two (C/2)-point
+    // images of L/2 + 16 each
+    constexpr int PER = L + 32;
+    static_assert(FftPlan<L>::LDS_ELEMS <= PER && 2 * FftPlan<L2>::LDS_ELEMS <= PER, "group region");
+    lds = smem + grp * PER;
+    cf *lds2 = lds + half * (PER / 2);
+    const int64_t AB = A * B, nslots = AB / 2 + 1;
+    const int side = grp >= HP ? 1 : 0;
+    const int pg = side ? grp - HP : grp;
+    auto look = [&](const BigTw &bt, int64_t m) __attribute__((always_inline)) { return cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]); };
+    for (int64_t s0 = (int64_t)blockIdx.x * HP; s0 < nslots; s0 += (int64_t)gridDim.x * HP) {
+        const int64_t s = s0 + pg;
+        const bool slot_ok = s < nslots;
+        const int64_t sc = slot_ok ? s : 0;
+        int64_t ka, kb;
+        bool self = false;
+        if (sc < AB / 2 - B) {
+            const int64_t j = B + sc;
+            ka = j / B;
+            kb = j % B;
+        } else {
+            const int64_t s2 = sc - (AB / 2 - B);
+            if (s2 < B / 2 - 1) {
+                ka = 0;
+                kb = 1 + s2;
+            } else if (s2 < B - 1) {
+                ka = A / 2;
+                kb = s2 - (B / 2 - 1);
+            } else {
+                ka = 0;
+                kb = s2 == B - 1 ? 0 : B / 2;
+                self = true;
+            }
+        }
+        const int64_t kam = ka != 0 ? A - ka : 0, kbm = ka != 0 ? B - 1 - kb : (B - kb) % B;
+        const int64_t myka = side ? kam : ka, mykb = side ? kbm : kb;
+        const bool act = slot_ok && !(self && side);
+        cf *row = Tm + (myka * B + mykb) * (int64_t)L;
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = row[tid + C::T * t];
+        xf.fwd(v, lds, tid, L);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) lds[tid + C::T * t] = v[t];
+        __syncthreads();
+        const cf *pl = smem + (self ? grp : (side ? grp - HP : grp + HP)) * PER;
+        const bool zero_row = myka == 0 && mykb == 0;
+        cf zp[C::R / 2];
+#pragma unroll
+        for (int t = 0; t < C::R / 2; ++t) {
+            const int kc = tid + C::T * t;                       // < C/2
+            const cf a = v[t], bm = v[t + C::R / 2];             // Z[k], Z[M + k]
+            const cf am = pl[zero_row ? ((L - kc) & (L - 1)) : (L - 1 - kc)];              // Z[L - k]
+            const cf b = pl[zero_row ? ((L2 - kc) & (L - 1)) : (L2 - 1 - kc)];             // Z[M - k]
+            const int64_t k = myka + A * (mykb + B * (int64_t)kc);
+            const cf za = cmul(a, am), zb = cmul(b, bm);
+            const cf rk = mk(0.5f * za.y, 0.25f * (cnorm(a) - cnorm(am)));
+            const cf rmc = mk(0.5f * zb.y, -0.25f * (cnorm(b) - cnorm(bm)));              // conj R(M - k)
+            const cf w = look(btL, k);                                                    // W_L^k
+            const cf sm = rk + rmc, d = rk - rmc;
+            const cf tt = cmul(cconj(w), d);
+            zp[t] = mk(0.5f * (sm.x - tt.y), -0.5f * (sm.y + tt.x));
+        }
+        __syncthreads();                                         // every partner read is done: the images may be overwritten
+        // the row's C/2 values, re-dealt to the layout of a (C/2)-point transform (both halves of the group's threads take the
+        // same elements and run the same transform on their own image: one barrier structure for the whole workgroup)
+#pragma unroll
+        for (int t = 0; t < C::R / 2; ++t) lds[tid + C::T * t] = zp[t];
+        __syncthreads();
+        cf u[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) u[t] = lds[tid2 + T2 * t];
+        __syncthreads();
+        f2.template run<true>(u, lds2, lds2, tid2);
+        // inter-pass twiddle of the M-point transform: W_M^{m ka'}, m = kb A + ka (its column index), ka' = tid2 + T2 t
+        {
+            const int64_t m = mykb * A + myka;
+            if constexpr (C::R == 16) {
+                bigtw_apply16(u, btM, m * (int64_t)tid2, m * (int64_t)T2);
+            } else {
+#pragma unroll
+                for (int t = 0; t < C::R; ++t) u[t] = cmul(u[t], look(btM, m * (int64_t)(tid2 + T2 * t)));
+            }
+        }
+        if (act && half == 0) {
+            cf *orow = row;                                      // the first C/2 elements of its OWN row: [ka][kb][ka'] at row pitch C
+            //                                                      (packed half rows would land on rows other workgroups still read)
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) orow[tid2 + T2 * t] = u[t];
+        }
+        __syncthreads();
+    }
+}
+
+// last column pass of the ccf's half-length transform: plain forward transform along the column (no twiddle).  Columns (outer, col):
+// element i of the column at in[outer os + col + i es]; its NATURAL index is j = col + ncols (outer + nouter i) (the half rows lie at
+// row pitch C, ncols = C/2 of them used); written are the lags (RowsOut kind 3's output: element j holds M (r[2j] - i r[2j+1]))
+template <int L>
+__global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fft_cols_lag(
+    const cf *__restrict__ in, int64_t ncolblocks, int64_t nouter, int64_t es, int64_t os, XfTables tb, RowsOut ro) {
+    using X = XfPow2<L>;
+    using C = typename X::C;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    cf *smem = reinterpret_cast<cf *>(smem_raw);
+    const int grp = C::FPW == 1 ? 0 : (int)threadIdx.x % C::FPW;
+    const int tid = C::FPW == 1 ? (int)threadIdx.x : (int)threadIdx.x / C::FPW;
+    cf *lds = smem + grp * C::LDS_PER;
+    X xf;
+    xf.init(tb, tid);
+    const float nrm = (float)(2.0 * ro.mom[2] / (double)ro.Ltot);
+    const int64_t ncols = ncolblocks * C::FPW, total = ncolblocks * nouter;
+    for (int64_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+        const int64_t col = (idx % ncolblocks) * C::FPW + grp, outer = idx / ncolblocks;
+        const int64_t base = outer * os + col;
+        cf v[C::R];
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
+        xf.fwd(v, lds, tid, L);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) {
+            const int64_t j2 = 2 * (col + ncols * (outer + nouter * (int64_t)(tid + C::T * t)));
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int64_t i = j2 + e;
+                const float val = nrm * (e ? -v[t].y : v[t].x);
+                if (i < ro.n) ro.co[i + ro.n - 1] = val;
+                else if (i > ro.Ltot - ro.n) ro.co[i - ro.Ltot + ro.n - 1] = val;
+            }
+        }
     }
 }
 

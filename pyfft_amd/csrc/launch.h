@@ -103,7 +103,7 @@ int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_
                        int64_t out_es, int conj_in, int conj_out, float scale, const Xf &xf, BigTw bt);
 int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
                     int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n = 0,
-                    ColsIn ci = ColsIn{0, nullptr, nullptr, nullptr, 0});
+                    ColsIn ci = ColsIn{0, nullptr, nullptr, nullptr, 0}, int tw_outer = 0);
 int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B, int conj_out, float scale, const Xf &xf,
                         RowsOut ro = RowsOut{nullptr, 0, 0, nullptr});
 // elementwise / transpose pieces of the long paths (k_fft.hip)
@@ -189,6 +189,9 @@ int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m
 int launch_hilbert_mid(LaunchCtx c, cf *Z, int64_t M, BigTw bt);
 // half-length Hilbert with the middle step inside the row pass + the two adjoint column passes (k_hilbert_rowsmid, k_fft_cols_inv)
 int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, BigTw btN);
+// long ccf with the middle step and the half-length transform's first pass inside the row pass (k_xc_rowsmid, k_fft_cols_lag)
+int launch_xc_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, const Xf &xc2, BigTw btL, BigTw btM);
+int launch_fft_cols_lag(LaunchCtx c, const cf *in, int64_t ncols, int64_t nouter, int64_t es, int64_t os, const Xf &xf, RowsOut ro);
 int launch_fft_cols_inv(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
                         const Xf &xf, BigTw bt, float scale, const RowsOut *analytic);
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out,

@@ -2358,6 +2358,41 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
             // (the zero half is never loaded), lag re-ordering + real part in the last pass of the second
             BigFuse f1, f2;
             f1.ci = ColsIn{1, a, b, tb.d + 16, n};
+            if (big_three_pass(L / 2) && !env_flag("SP_XC_FULL") && !env_flag("SP_XC_NOFUSEMID")) {
+                // round 3: the forward transform's row pass, the middle step and the FIRST pass of the half-length transform in one
+                // kernel that owns mirror row pairs (k_xc_rowsmid); the half-length transform's two remaining passes are column
+                // passes over the half rows it leaves ([ka][kb][ka'], C/2 per row), the last one writing the lags
+                int lg = 0;
+                while (((int64_t)1 << lg) < L) ++lg;
+                int la_ = (lg + 2) / 3;
+                if (la_ > 8) la_ = 8;
+                int lb_ = (lg - la_ + 1) / 2;
+                if (lb_ > 8) lb_ = 8;
+                const int lc_ = lg - la_ - lb_;
+                const int64_t Aa = (int64_t)1 << la_, Bb = (int64_t)1 << lb_, Cc = (int64_t)1 << lc_, C2 = Cc / 2;
+                Xf xa, xb, xc, xc2;
+                BigTw btL, btM;
+                if (get_xf(Aa, &xa) || get_xf(Bb, &xb) || get_xf(Cc, &xc) || get_xf(C2, &xc2) || get_bigtw(L, &btL) ||
+                    get_bigtw(L / 2, &btM))
+                    return -1;
+                if (Aa >= 64 && Aa <= 256 && Bb >= 64 && Bb <= 256 && Cc >= 64 && Cc <= 2048) {
+                    LAUNCHCHK(launch_fft_cols(lc(), A, A, Bb * Cc, 1, Bb * Cc, 0, 1, 0, xa, btL, 0, f1.ci));
+                    LAUNCHCHK(launch_fft_cols(lc(), A, A, Cc, Aa, Cc, Bb * Cc, Aa, 0, xb, btL));
+                    LAUNCHCHK(launch_xc_rowsmid(lc(), A, Aa, Bb, xc, xc2, btL, btM));
+                    // M-point transform, split (A' = C/2 [done], B' = B, C' = A) on the layout [ka][kb][ka']:
+                    //   over kb (stride = the row pitch C, columns ka' < C/2, outer ka), twiddle W_M^{A' ka kb''}: by the OUTER index
+                    LAUNCHCHK(launch_fft_cols(lc(), A, A, C2, Aa, Cc, Bb * Cc, C2, 0, xb, btM, 0, ColsIn{0, nullptr, nullptr, nullptr, 0}, 1));
+                    //   over ka (stride B C): natural index k' = ka' + A' kb'' + A' B' kc''; the lags leave from here
+                    RowsOut ro{od, n, L, tb.d + 16};
+                    ro.kind = 3;
+                    LAUNCHCHK(launch_fft_cols_lag(lc(), A, C2, Bb, Bb * Cc, Cc, xa, ro));
+                    if (!mem) {
+                        HIPCHK(hipMemcpyAsync(co_out, od, obytes, hipMemcpyDeviceToHost, g.stream));
+                        HIPCHK(hipStreamSynchronize(g.stream));
+                    }
+                    return 0;
+                }
+            }
             if (dev_fft_big_pow2(A, B, L, 0, 0, 1, &f1)) return -1;          // B = FFT(z)
             if (big_three_pass(L / 2) && !env_flag("SP_XC_FULL")) {
                 // the correlation is real: its inverse transform runs at half length (k_xc_mid_half forms the M-point spectrum

@@ -777,6 +777,31 @@ def test_xcorr_long(E, n):
     assert np.argmax(co) == np.argmax(ref)
 
 
+@pytest.mark.parametrize("n", [600001, 1100003, 1 << 21, (1 << 22) + 7, 1 << 23, 1 << 24])
+def test_xcorr_long_middle_step_in_the_row_pass(E, n):
+    """round 3: the forward transform's row pass, k_xc_mid_half's arithmetic and the first pass of the half-length transform in ONE
+    kernel that owns mirror row pairs (k_xc_rowsmid), the lags written by the last column pass (k_fft_cols_lag).  Every
+    three-pass split from 2^21 to 2^25 points; against the separate-middle-step form (SP_XC_NOFUSEMID=1) everywhere and the
+    oracle's FFT formulation (ccf.py:66-77 restated) where that is quick."""
+    import os
+    rng = np.random.default_rng(n % 997)
+    k = np.arange(n)
+    x1 = (np.sin(0.01 * k) + rng.standard_normal(n) + 1.5).astype(np.float32)
+    x2 = (np.roll(x1, 41) + 0.5 * rng.standard_normal(n) - 0.5).astype(np.float32)
+    co = E.xcorr_normalised(x1, x2)
+    os.environ["SP_XC_NOFUSEMID"] = "1"
+    try:
+        co0 = E.xcorr_normalised(x1, x2)
+    finally:
+        del os.environ["SP_XC_NOFUSEMID"]
+    assert co.shape == co0.shape == (2 * n - 1,)
+    assert np.max(np.abs(co - co0)) <= 2e-5 * np.abs(co0).max()
+    assert np.argmax(co) == np.argmax(co0) == (n - 1) - 41
+    if n <= (1 << 22) + 7:
+        tau, ref = O.ccf_fft(x1.astype(np.float64), x2.astype(np.float64), 1.0)
+        assert np.max(np.abs(co - ref)) <= 1e-4 * np.abs(ref).max()
+
+
 # ---------------------------------------------------------------- F1 FIR
 @pytest.mark.parametrize("ntaps,n,nfft", [(513, 40000, 4096), (513, 40000, 0), (31, 5000, 1024), (2, 100, 64),
                                            (1, 1000, 256), (4097, 20000, 8192)])
