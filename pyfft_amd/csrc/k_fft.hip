@@ -32,12 +32,29 @@ int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_
 int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
                     int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n, ColsIn ci, int tw_outer) {
     if (xf.blue) return -1;
-    const int fpw = fpw_of(xf.L);
+    int fpw = fpw_of(xf.L);
     if (ncols % fpw || nouter < 1) return -1;
+    // first passes on real samples (kind 1 / 3), 256-point columns: 512-thread workgroups that own 32 adjacent columns (WM = 2,
+    // SP_COLS_WIDE=1).  Measured SLOWER than 16 columns (round 3: 70.9 against 63.1 us for the Hilbert's first pass at 2^23 points,
+    // 196.9 against 147.4 for the ccf's at 2^25): one workgroup per CU instead of two, and the twice as long row segments do
+    // not pay for it.  Off by default.
+    static const bool wide_ok = getenv("SP_COLS_WIDE") && getenv("SP_COLS_WIDE")[0] == '1';
+    const bool wide = wide_ok && (ci.kind == 1 || ci.kind == 3) && xf.L == 256 && hmask_n == 0 && ncols % (2 * fpw) == 0;
+    if (wide) fpw *= 2;
     const int64_t ncb = ncols / fpw, total = ncb * nouter;
     // (a multiple of the 2 or 3 workgroups a CU holds, so that the last round is a full one)
-    const int64_t cap = (int64_t)c.ncu * 6;                    // several blocks per workgroup amortise its twiddle set-up
+    const int64_t cap = (int64_t)c.ncu * (wide ? 3 : 6);       // several blocks per workgroup amortise its twiddle set-up
     const unsigned grid = (unsigned)(total < cap ? total : cap);
+    if (wide) {
+        using XT = XfPow2<256>;
+        if (ci.kind == 1)
+            hipLaunchKernelGGL((k_fft_cols<256, 1, false, 2>), dim3(grid), dim3(XT::C::WG * 2), XT::C::lds_bytes(1) * 2, c.stream, in, out, ncb,
+                               nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer);
+        else
+            hipLaunchKernelGGL((k_fft_cols<256, 3, false, 2>), dim3(grid), dim3(XT::C::WG * 2), XT::C::lds_bytes(1) * 2, c.stream, in, out, ncb,
+                               nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer);
+        return 0;
+    }
 #define M_(XT)                                                                                        \
     if (ci.kind == 1) hipLaunchKernelGGL((k_fft_cols<XT::L, 1>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, \
                                          ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer);       \

@@ -27,6 +27,12 @@ template <int L> struct WgCfg {
     static constexpr size_t lds_bytes(int nbuf) { return (size_t)FPW * LDS_PER * sizeof(cf) * nbuf; }
 };
 
+// the same with the workgroup widened WM times (more transforms per workgroup, same per-transform constants)
+template <int L, int WM> struct WgCfgW {
+    using B = WgCfg<L>;
+    static constexpr int R = B::R, T = B::T, WG = B::WG * WM, FPW = B::FPW * WM, LDS_PER = B::LDS_PER;
+};
+
 // device tables of one transform length
 struct XfTables {
     const cf *tw;      // exp(-2 pi i m/L), m < L
@@ -408,14 +414,17 @@ struct ColsIn {
 #ifndef SP_COLS_WAVES
 #define SP_COLS_WAVES 3
 #endif
-template <int L, int KIND, bool HM = false>   // KIND = ci.kind as a template parameter: as a run-time branch the load forms cost 306 VGPRs
-__global__ __launch_bounds__(WgCfg<L>::WG)
+// WM: workgroup width multiplier -- WM = 2 gives a workgroup 2 FPW adjacent columns (512 threads at L = 256: 32 columns, so every
+// row access is 256 contiguous bytes of complex data / 128 of real samples instead of 128 / 64).  Used for the FIRST pass of the long
+// transforms (KIND 1 / 3: real samples at a stride of B C -- 64-byte pieces a megabyte apart ran at 2.0-2.7 TB/s)
+template <int L, int KIND, bool HM = false, int WM = 1>   // KIND = ci.kind as a template parameter: as a run-time branch the load forms cost 306 VGPRs
+__global__ __launch_bounds__(WgCfg<L>::WG * WM)
     __attribute__((amdgpu_waves_per_eu((KIND == 0 && !HM && L <= 256) ? SP_COLS_WAVES : 2,
                                        (KIND == 0 && !HM && L <= 256) ? SP_COLS_WAVES : 2))) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
                                                             int64_t nouter, int64_t es, int64_t os, int64_t twmul, int conj_in,
                                                             XfTables tb, BigTw bt, int64_t hmask_n, ColsIn ci, int tw_outer = 0) {
     using X = XfPow2<L>;
-    using C = typename X::C;
+    using C = WgCfgW<L, WM>;                      // the plan's constants with the widened workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     cf *smem = reinterpret_cast<cf *>(smem_raw);
     const int grp = C::FPW == 1 ? 0 : (int)threadIdx.x % C::FPW;
