@@ -13,7 +13,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n = r["Name"]
-    if any(k in n for k in ("k_fft_cols", "k_fft_rows_rev", "k_hilbert_mid", "k_xc_mid", "k_moments", "k_hilbert<")):
+    if any(k in n for k in ("k_fft_cols", "k_fft_rows_rev", "k_hilbert_mid", "k_xc_mid", "k_moments", "k_hilbert<", "rowsmid", "k_xcorr_norm")):
         print("%-90s calls %5s  avg %9.1f us" % (n[:90], r["Calls"], float(r["AverageNs"]) / 1e3))
 PY
 done
