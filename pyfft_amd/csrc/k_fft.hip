@@ -28,6 +28,14 @@ int launch_fft_strided(LaunchCtx c, const cf *in, cf *out, int64_t batch, int64_
     return 0;
 }
 
+static bool env_cols_noxpair() {
+    const char *e = getenv("SP_COLS_NOXPAIR");     // A/B switch (read per call)
+    return e && e[0] == '1';
+}
+static bool env_cols_nohalf() {
+    const char *e = getenv("SP_COLS_NOHALF");      // A/B switch of the tests (read per call)
+    return e && e[0] == '1';
+}
 // three-pass long transform pieces (power-of-two lengths; ncols is a multiple of the columns per workgroup)
 int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
                     int conj_in, const Xf &xf, BigTw bt, int64_t hmask_n, ColsIn ci, int tw_outer) {
@@ -55,8 +63,15 @@ int launch_fft_cols(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64_t n
                                nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer);
         return 0;
     }
+    // real samples in (kind 1 / 4: 64-byte pieces per row and array): pair neighbouring column blocks on one XCD
+    if ((ci.kind == 1 || ci.kind == 4) && total % 16 == 0 && grid % 16 == 0 && !env_cols_noxpair()) tw_outer |= 2;
+    // kind 1 whose samples end exactly at the middle row: the predicate-free form
+    const bool half_exact = ci.kind == 1 && ci.r2 && ci.mom && nouter == 1 && xf.L >= 32 && ci.nreal == (int64_t)(xf.L / 2) * es &&
+                            !env_cols_nohalf();
 #define M_(XT)                                                                                        \
-    if (ci.kind == 1) hipLaunchKernelGGL((k_fft_cols<XT::L, 1>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, \
+    if (half_exact) hipLaunchKernelGGL((k_fft_cols<XT::L, 4>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, \
+                                       ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer);       \
+    else if (ci.kind == 1) hipLaunchKernelGGL((k_fft_cols<XT::L, 1>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, \
                                          ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer);       \
     else if (ci.kind == 3) hipLaunchKernelGGL((k_fft_cols<XT::L, 3>), dim3(grid), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, \
                                               out, ncb, nouter, es, os, twmul, conj_in, xf.tb, bt, hmask_n, ci, tw_outer); \
@@ -136,6 +151,7 @@ int launch_fft_cols_lag(LaunchCtx c, const cf *in, int64_t ncols, int64_t nouter
     if (ncols % fpw || nouter < 1) return -1;
     const int64_t ncb = ncols / fpw, total = ncb * nouter, cap = (int64_t)c.ncu * 6;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
+    if (total % 16 == 0 && grid % 16 == 0 && !env_cols_noxpair()) ro.kind |= 16;
 #define CL_(LL)                                                                                        \
     case LL:                                                                                          \
         hipLaunchKernelGGL((k_fft_cols_lag<LL>), dim3(grid), dim3(WgCfg<LL>::WG), WgCfg<LL>::lds_bytes(1), c.stream, in, ncb, nouter, es, os, \
@@ -156,9 +172,13 @@ int launch_fft_cols_inv(LaunchCtx c, const cf *in, cf *out, int64_t ncols, int64
     const int64_t ncb = ncols / fpw, total = ncb * nouter, cap = (int64_t)c.ncu * 6;
     const unsigned grid = (unsigned)(total < cap ? total : cap);
     const RowsOut ro = analytic ? *analytic : RowsOut{nullptr, 0, 0, nullptr};
+    // the whole row holds samples and pairs are 8-byte aligned: the predicate-free output form
+    const bool full = analytic && ro.n == ro.Ltot && (((uintptr_t)ro.rx) & 7) == 0 && !env_cols_nohalf();
 #define CI_(LL)                                                                                        \
     case LL:                                                                                          \
-        if (analytic) hipLaunchKernelGGL((k_fft_cols_inv<LL, 2>), dim3(grid), dim3(WgCfg<LL>::WG), WgCfg<LL>::lds_bytes(1), c.stream, in, out, \
+        if (analytic && full) hipLaunchKernelGGL((k_fft_cols_inv<LL, 3>), dim3(grid), dim3(WgCfg<LL>::WG), WgCfg<LL>::lds_bytes(1), c.stream, in, out, \
+                                         ncb, nouter, es, os, twmul, xf.tb, bt, scale, ro);           \
+        else if (analytic) hipLaunchKernelGGL((k_fft_cols_inv<LL, 2>), dim3(grid), dim3(WgCfg<LL>::WG), WgCfg<LL>::lds_bytes(1), c.stream, in, out, \
                                          ncb, nouter, es, os, twmul, xf.tb, bt, scale, ro);           \
         else hipLaunchKernelGGL((k_fft_cols_inv<LL, 0>), dim3(grid), dim3(WgCfg<LL>::WG), WgCfg<LL>::lds_bytes(1), c.stream, in, out, ncb, \
                                 nouter, es, os, twmul, xf.tb, bt, scale, ro);                         \

@@ -402,6 +402,8 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_fft_strided(const cf *__restri
 //           (long Hilbert: z[n] = x[2n] + i x[2n+1], M = N/2 points)
 // (ccf's middle step, R[k] from Z[k] and Z[L-k], was tried as a third form: 388 VGPRs, 132 spilled at the 2-wave cap --
 //  it stays its own kernel, k_xc_mid; so does the half-length Hilbert's, k_hilbert_mid)
+// workgroup index -> block index with blocks 2m, 2m + 1 on workgroups w, w + 8 (a bijection on every aligned run of 16)
+__device__ __forceinline__ int64_t xcd_pair(int64_t w) { return (w & ~(int64_t)15) | ((w & 7) << 1) | ((w >> 3) & 1); }
 struct ColsIn {
     int kind;
     const float *r1, *r2;
@@ -419,8 +421,8 @@ struct ColsIn {
 // transforms (KIND 1 / 3: real samples at a stride of B C -- 64-byte pieces a megabyte apart ran at 2.0-2.7 TB/s)
 template <int L, int KIND, bool HM = false, int WM = 1>   // KIND = ci.kind as a template parameter: as a run-time branch the load forms cost 306 VGPRs
 __global__ __launch_bounds__(WgCfg<L>::WG * WM)
-    __attribute__((amdgpu_waves_per_eu((KIND == 0 && !HM && L <= 256) ? SP_COLS_WAVES : 2,
-                                       (KIND == 0 && !HM && L <= 256) ? SP_COLS_WAVES : 2))) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
+    __attribute__((amdgpu_waves_per_eu(((KIND == 0 || KIND == 4) && !HM && L <= 256) ? SP_COLS_WAVES : 2,
+                                       ((KIND == 0 || KIND == 4) && !HM && L <= 256) ? SP_COLS_WAVES : 2))) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
                                                             int64_t nouter, int64_t es, int64_t os, int64_t twmul, int conj_in,
                                                             XfTables tb, BigTw bt, int64_t hmask_n, ColsIn ci, int tw_outer = 0) {
     using X = XfPow2<L>;
@@ -436,7 +438,10 @@ __global__ __launch_bounds__(WgCfg<L>::WG * WM)
     // a workgroup walks over (outer, column block) pairs with the grid as stride: the twiddle set-up is paid once per
     // workgroup, and at any time neighbouring workgroups read neighbouring 128-byte segments of the same rows
     const int64_t total = nouter * ncolblocks;
-    for (int64_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    for (int64_t widx = blockIdx.x; widx < total; widx += gridDim.x) {
+        // (tw_outer bit 1, set by the launcher when the grid and the block count are multiples of 16: column blocks 2m and 2m + 1 go
+        //  to workgroups 8 apart = the same XCD, so that the two 64-byte halves of a 128-byte line of REAL samples meet in one L2)
+        const int64_t idx = (tw_outer & 2) ? xcd_pair(widx) : widx;
         const int64_t col = (idx % ncolblocks) * C::FPW + grp;
         const int64_t base = (idx / ncolblocks) * os + col;
         cf v[C::R];
@@ -449,6 +454,19 @@ __global__ __launch_bounds__(WgCfg<L>::WG * WM)
                 const int64_t ic = ok ? i : 0;
                 const float a = ci.r1[ic], b = ci.r2 ? ci.r2[ic] : m2;
                 v[t] = ok ? mk(a - m1, b - m2) : mk(0.f, 0.f);
+            }
+        } else if constexpr (KIND == 4) {
+            // kind 1 when the samples end exactly at the middle row (nreal = L/2 * es: a power-of-two ccf): slots t < R/2 are
+            // all samples, the others all padding -- no predicates, no 64-bit compares, and the zeros fold into the first butterfly
+            const float m1 = (float)ci.mom[0], m2 = (float)ci.mom[1];
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                if (t < C::R / 2) {
+                    const int64_t i = base + (int64_t)(tid + C::T * t) * es;
+                    v[t] = mk(ci.r1[i] - m1, ci.r2[i] - m2);
+                } else {
+                    v[t] = mk(0.f, 0.f);
+                }
             }
         } else if constexpr (KIND == 3) {
             if (ci.r2 != nullptr) {
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(WgCfg<L>::WG * WM)
         xf.fwd(v, lds, tid, L);
         // (tw_outer: the twiddle is indexed by the OUTER index instead of the column -- the ccf's half rows [ka][kb][ka'], where
         //  the M-point transform's column index c' = ka is the outer one of the pass over kb)
-        const int64_t mc = twmul * (tw_outer ? idx / ncolblocks : col);
+        const int64_t mc = twmul * ((tw_outer & 1) ? idx / ncolblocks : col);
 #if SP_BIGTW_REC
         if constexpr (C::R == 16) {
             // W^{mc (tid + T t)} = W^{mc tid} (W^{mc T})^t: two table look-ups per thread instead of sixteen (each look-up is
@@ -675,6 +693,9 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_hilbert_rowsmid(cf *__restrict
 // FFT_{C/2} -> the inter-pass twiddle W_M^{(kb A + ka) ka'} -> half rows [ka][kb][ka'] in place (row pitch C); two column passes follow (over
 // kb with the twiddle indexed by the OUTER index ka, then over ka), the last one writing the lags.  1.9 GB instead of 3.0 GB at
 // 2^24 samples, 5 launches instead of 7.
+#ifndef SP_XCROWS_PREFETCH
+#define SP_XCROWS_PREFETCH 1
+#endif
 template <int L>
 __global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm, int64_t A, int64_t B, XfTables tb, XfTables tb2,
                                                             BigTw btL, BigTw btM) {
@@ -698,7 +719,12 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm
     const int side = grp >= HP ? 1 : 0;
     const int pg = side ? grp - HP : grp;
     auto look = [&](const BigTw &bt, int64_t m) __attribute__((always_inline)) { return cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]); };
-    for (int64_t s0 = (int64_t)blockIdx.x * HP; s0 < nslots; s0 += (int64_t)gridDim.x * HP) {
+    // slot -> the group's row (ka, kb) of the pair (side 0) or its mirror row (side 1); self: the two rows that are their own mirror
+    struct Slot {
+        int64_t myka, mykb;
+        bool act, self;
+    };
+    auto decode = [&](int64_t s0) __attribute__((always_inline)) {
         const int64_t s = s0 + pg;
         const bool slot_ok = s < nslots;
         const int64_t sc = slot_ok ? s : 0;
@@ -723,12 +749,38 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm
             }
         }
         const int64_t kam = ka != 0 ? A - ka : 0, kbm = ka != 0 ? B - 1 - kb : (B - kb) % B;
-        const int64_t myka = side ? kam : ka, mykb = side ? kbm : kb;
-        const bool act = slot_ok && !(self && side);
+        return Slot{side ? kam : ka, side ? kbm : kb, slot_ok && !(self && side), self};
+    };
+    // the NEXT slot's rows are loaded while this one is transformed (SP_XCROWS_PREFETCH: the loop ran load -> two transforms -> store
+    // with two workgroups per CU; no other workgroup writes a slot's rows, so the early read is safe)
+    const int64_t sstep = (int64_t)gridDim.x * HP;
+    cf v[C::R];
+#if SP_XCROWS_PREFETCH
+    {
+        const Slot s1 = decode((int64_t)blockIdx.x * HP);
+        const cf *r1 = Tm + (s1.myka * B + s1.mykb) * (int64_t)L;
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = r1[tid + C::T * t];
+    }
+#endif
+    for (int64_t s0 = (int64_t)blockIdx.x * HP; s0 < nslots; s0 += sstep) {
+        const Slot sl = decode(s0);
+        const int64_t myka = sl.myka, mykb = sl.mykb;
+        const bool act = sl.act, self = sl.self;
         cf *row = Tm + (myka * B + mykb) * (int64_t)L;
-        cf v[C::R];
+#if SP_XCROWS_PREFETCH
+        cf vn[C::R];
+        {
+            const Slot s2 = decode(s0 + sstep < nslots ? s0 + sstep : s0);       // (the last iteration re-reads its own rows: unused)
+            const cf *r2 = Tm + (s2.myka * B + s2.mykb) * (int64_t)L;
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) vn[t] = r2[tid + C::T * t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#else
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = row[tid + C::T * t];
+#endif
         xf.fwd(v, lds, tid, L);
         __syncthreads();
 #pragma unroll
@@ -736,6 +788,9 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm
         __syncthreads();
         const cf *pl = smem + (self ? grp : (side ? grp - HP : grp + HP)) * PER;
         const bool zero_row = myka == 0 && mykb == 0;
+        // W_L^k = W_L^{ka + A kb} W_C^{kc} (L = A B C): one look-up in the two-level table per row, the rest from the C-point
+        // transform's own twiddle table (4 KiB, L1-resident) -- instead of eight scattered two-level look-ups per thread
+        const cf w0 = look(btL, myka + A * mykb);
         cf zp[C::R / 2];
 #pragma unroll
         for (int t = 0; t < C::R / 2; ++t) {
@@ -747,7 +802,8 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm
             const cf za = cmul(a, am), zb = cmul(b, bm);
             const cf rk = mk(0.5f * za.y, 0.25f * (cnorm(a) - cnorm(am)));
             const cf rmc = mk(0.5f * zb.y, -0.25f * (cnorm(b) - cnorm(bm)));              // conj R(M - k)
-            const cf w = look(btL, k);                                                    // W_L^k
+            (void)k;
+            const cf w = cmul(w0, tb.tw[kc]);                                             // W_L^k
             const cf sm = rk + rmc, d = rk - rmc;
             const cf tt = cmul(cconj(w), d);
             zp[t] = mk(0.5f * (sm.x - tt.y), -0.5f * (sm.y + tt.x));
@@ -780,12 +836,20 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm
             for (int t = 0; t < C::R; ++t) orow[tid2 + T2 * t] = u[t];
         }
         __syncthreads();
+#if SP_XCROWS_PREFETCH
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) v[t] = vn[t];
+#endif
     }
 }
 
 // last column pass of the ccf's half-length transform: plain forward transform along the column (no twiddle).  Columns (outer, col):
 // element i of the column at in[outer os + col + i es]; its NATURAL index is j = col + ncols (outer + nouter i) (the half rows lie at
 // row pitch C, ncols = C/2 of them used); written are the lags (RowsOut kind 3's output: element j holds M (r[2j] - i r[2j+1]))
+#ifndef SP_COLSX_WAVES
+#define SP_COLSX_WAVES 3          // k_fft_cols_inv, complex output: three workgroups per CU for this unpipelined loop (161 VGPRs, no spills;
+                                  // the forms with the analytic-signal / lag output spill 21-51 registers at three and stay at two)
+#endif
 template <int L>
 __global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fft_cols_lag(
     const cf *__restrict__ in, int64_t ncolblocks, int64_t nouter, int64_t es, int64_t os, XfTables tb, RowsOut ro) {
@@ -800,7 +864,10 @@ __global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(2,
     xf.init(tb, tid);
     const float nrm = (float)(2.0 * ro.mom[2] / (double)ro.Ltot);
     const int64_t ncols = ncolblocks * C::FPW, total = ncolblocks * nouter;
-    for (int64_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+    for (int64_t widx = blockIdx.x; widx < total; widx += gridDim.x) {
+        // (ro.kind bit 4: neighbouring column blocks on one XCD -- their lag segments are 128 bytes at an odd float offset, so every
+        //  output line is shared by two blocks)
+        const int64_t idx = (ro.kind & 16) ? xcd_pair(widx) : widx;
         const int64_t col = (idx % ncolblocks) * C::FPW + grp, outer = idx / ncolblocks;
         const int64_t base = outer * os + col;
         cf v[C::R];
@@ -826,7 +893,7 @@ __global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(2,
 // index j = base + i es is the sample-pair index, written is the analytic signal a[2j] = rx[2j] + i scale Re, a[2j+1] = rx[2j+1] + i
 // scale Im (RowsOut kind 2's output, 16 adjacent columns = 256 contiguous bytes per row).
 template <int L, int OUT>
-__global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_fft_cols_inv(
+__global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(OUT == 0 ? SP_COLSX_WAVES : 2, OUT == 0 ? SP_COLSX_WAVES : 2))) void k_fft_cols_inv(
     const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks, int64_t nouter, int64_t es, int64_t os, int64_t twmul,
     XfTables tb, BigTw bt, float scale, RowsOut ro) {
     using X = XfPow2<L>;
@@ -859,7 +926,17 @@ __global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(2,
             }
         }
         xf.fwd(v, lds, tid, L);
-        if constexpr (OUT == 2) {
+        if constexpr (OUT == 3) {
+            // OUT 2 for a full, 8-byte aligned row (ro.n = Ltot): the sample pair as one load, no predicates
+            float4 *ao = reinterpret_cast<float4 *>(ro.co);
+            const cf *xp = reinterpret_cast<const cf *>(ro.rx);
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                const int64_t j = base + (int64_t)(tid + C::T * t) * es;
+                const cf xx = xp[j];
+                ao[j] = make_float4(xx.x, scale * v[t].x, xx.y, -scale * v[t].y);
+            }
+        } else if constexpr (OUT == 2) {
             float4 *ao = reinterpret_cast<float4 *>(ro.co);
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {

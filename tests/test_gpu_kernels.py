@@ -737,6 +737,15 @@ def test_hilbert_long_middle_step_in_the_row_pass(E, log2n):
     if log2n <= 23:
         ref = O.hilbert(u.astype(np.float64))
         assert np.max(np.abs(z - ref)) <= 2e-5 * np.abs(ref).max()
+    if log2n in (21, 24):
+        # the full, aligned row takes the predicate-free end passes (plain first pass on the samples seen as complex pairs,
+        # k_fft_cols_inv<., 3>); against the predicated forms
+        os.environ["SP_COLS_NOHALF"] = os.environ["SP_HILBERT_PAIRLOAD"] = "1"
+        try:
+            z1 = E.hilbert_rows(u[None, :], n)[0]
+        finally:
+            del os.environ["SP_COLS_NOHALF"], os.environ["SP_HILBERT_PAIRLOAD"]
+        assert np.max(np.abs(z - z1)) <= 1e-6 * np.abs(z1).max()
     nuse = n - 12345                                                  # truncated / zero-padded row
     z = E.hilbert_rows(u[None, :nuse], n)[0]
     os.environ["SP_HILBERT_NOFUSEMID"] = "1"
@@ -796,6 +805,15 @@ def test_xcorr_long_middle_step_in_the_row_pass(E, n):
         del os.environ["SP_XC_NOFUSEMID"]
     assert co.shape == co0.shape == (2 * n - 1,)
     assert np.max(np.abs(co - co0)) <= 2e-5 * np.abs(co0).max()
+    if n & (n - 1) == 0:
+        # power-of-two sample counts end exactly at the middle row of the first pass: the predicate-free pack (k_fft_cols<., 4>)
+        # against the predicated one
+        os.environ["SP_COLS_NOHALF"] = "1"
+        try:
+            co1 = E.xcorr_normalised(x1, x2)
+        finally:
+            del os.environ["SP_COLS_NOHALF"]
+        assert np.max(np.abs(co - co1)) <= 1e-6 * np.abs(co1).max()
     assert np.argmax(co) == np.argmax(co0) == (n - 1) - 41
     if n <= (1 << 22) + 7:
         tau, ref = O.ccf_fft(x1.astype(np.float64), x2.astype(np.float64), 1.0)
