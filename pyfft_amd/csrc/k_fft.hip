@@ -110,7 +110,7 @@ int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B
 
 int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, BigTw btN) {
     if (xc.blue || A < 2 || B < 2) return -1;
-    const int64_t nslots = A * B / 2 + 1;
+    const int64_t nslots = A * B / 2;
 #define RM_(LL)                                                                                        \
     case LL: {                                                                                        \
         constexpr int HP = WgCfg<LL>::FPW / 2;                                                        \
@@ -128,7 +128,7 @@ int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &
 
 int launch_xc_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, const Xf &xc2, BigTw btL, BigTw btM) {
     if (xc.blue || xc2.blue || xc2.L * 2 != xc.L || A < 2 || B < 2) return -1;
-    const int64_t nslots = A * B / 2 + 1;
+    const int64_t nslots = A * B / 2;
 #define XR_(LL)                                                                                        \
     case LL: {                                                                                        \
         constexpr int HP = WgCfg<LL>::FPW / 2;                                                        \

@@ -416,13 +416,18 @@ struct ColsIn {
 #ifndef SP_COLS_WAVES
 #define SP_COLS_WAVES 3
 #endif
+// SP_COLS_PREFETCH=1: the plain form (KIND 0, no mask) loads the NEXT block's column elements before it transforms this one, at two
+// workgroups per CU (32 more registers) instead of three unpipelined ones
+#ifndef SP_COLS_PREFETCH
+#define SP_COLS_PREFETCH 0
+#endif
 // WM: workgroup width multiplier -- WM = 2 gives a workgroup 2 FPW adjacent columns (512 threads at L = 256: 32 columns, so every
 // row access is 256 contiguous bytes of complex data / 128 of real samples instead of 128 / 64).  Used for the FIRST pass of the long
 // transforms (KIND 1 / 3: real samples at a stride of B C -- 64-byte pieces a megabyte apart ran at 2.0-2.7 TB/s)
 template <int L, int KIND, bool HM = false, int WM = 1>   // KIND = ci.kind as a template parameter: as a run-time branch the load forms cost 306 VGPRs
 __global__ __launch_bounds__(WgCfg<L>::WG * WM)
-    __attribute__((amdgpu_waves_per_eu(((KIND == 0 || KIND == 4) && !HM && L <= 256) ? SP_COLS_WAVES : 2,
-                                       ((KIND == 0 || KIND == 4) && !HM && L <= 256) ? SP_COLS_WAVES : 2))) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
+    __attribute__((amdgpu_waves_per_eu((((KIND == 0 && !SP_COLS_PREFETCH) || KIND == 4) && !HM && L <= 256) ? SP_COLS_WAVES : 2,
+                                       (((KIND == 0 && !SP_COLS_PREFETCH) || KIND == 4) && !HM && L <= 256) ? SP_COLS_WAVES : 2))) void k_fft_cols(const cf *__restrict__ in, cf *__restrict__ out, int64_t ncolblocks,
                                                             int64_t nouter, int64_t es, int64_t os, int64_t twmul, int conj_in,
                                                             XfTables tb, BigTw bt, int64_t hmask_n, ColsIn ci, int tw_outer = 0) {
     using X = XfPow2<L>;
@@ -438,6 +443,17 @@ __global__ __launch_bounds__(WgCfg<L>::WG * WM)
     // a workgroup walks over (outer, column block) pairs with the grid as stride: the twiddle set-up is paid once per
     // workgroup, and at any time neighbouring workgroups read neighbouring 128-byte segments of the same rows
     const int64_t total = nouter * ncolblocks;
+    constexpr bool PF = SP_COLS_PREFETCH && KIND == 0 && !HM;
+    auto base_of = [&](int64_t w) __attribute__((always_inline)) {
+        const int64_t ix = (tw_outer & 2) ? xcd_pair(w) : w;
+        return (ix / ncolblocks) * os + (ix % ncolblocks) * C::FPW + grp;
+    };
+    cf vpf[PF ? C::R : 1];
+    if constexpr (PF) {
+        const int64_t b0 = base_of((int64_t)blockIdx.x < total ? (int64_t)blockIdx.x : 0);
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) vpf[t] = in[b0 + (int64_t)(tid + C::T * t) * es];
+    }
     for (int64_t widx = blockIdx.x; widx < total; widx += gridDim.x) {
         // (tw_outer bit 1, set by the launcher when the grid and the block count are multiples of 16: column blocks 2m and 2m + 1 go
         //  to workgroups 8 apart = the same XCD, so that the two 64-byte halves of a 128-byte line of REAL samples meet in one L2)
@@ -489,6 +505,15 @@ __global__ __launch_bounds__(WgCfg<L>::WG * WM)
                     v[t] = mk(ok0 ? a : 0.f, ok1 ? b : 0.f);
                 }
             }
+        } else if constexpr (PF) {
+            // (no other workgroup writes the next block's columns, also in place: the early read is safe)
+            const int64_t bn = base_of(widx + gridDim.x < total ? widx + gridDim.x : widx);
+#pragma unroll
+            for (int t = 0; t < C::R; ++t) {
+                v[t] = vpf[t];
+                vpf[t] = in[bn + (int64_t)(tid + C::T * t) * es];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         } else {
 #pragma unroll
             for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
@@ -617,7 +642,9 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_hilbert_rowsmid(cf *__restrict
     (void)n;
     static_assert(C::FPW >= 2 && (C::FPW % 2) == 0, "a workgroup holds rows and their mirror rows");
     constexpr int HP = C::FPW / 2;                               // row pairs per workgroup and iteration
-    const int64_t AB = A * B, nslots = AB / 2 + 1;               // pairs + the two self-mirrored rows (0, 0), (0, B/2)
+    const int64_t AB = A * B, nslots = AB / 2;                   // pairs + ONE slot for the two self-mirrored rows (0, 0), (0, B/2):
+                                                                 // a power of two, so that the workgroups' iteration counts are equal
+                                                                 // (with a slot each, one workgroup ran a third iteration after all others' two)
     const int side = grp >= HP ? 1 : 0;
     const int pg = side ? grp - HP : grp;
     auto look = [&](int64_t m) __attribute__((always_inline)) { return cmul(btN.hi[m >> btN.lb], btN.lo[m & ((1 << btN.lb) - 1)]); };
@@ -639,15 +666,15 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_hilbert_rowsmid(cf *__restrict
             } else if (s2 < B - 1) {                             // (A/2, kb), kb < B/2  <->  (A/2, B - 1 - kb)
                 ka = A / 2;
                 kb = s2 - (B / 2 - 1);
-            } else {                                             // the two rows that are their own mirror
-                ka = 0;
-                kb = s2 == B - 1 ? 0 : B / 2;
+            } else {                                             // the two rows that are their own mirror: side 0 takes (0, 0),
+                ka = 0;                                          // side 1 takes (0, B/2); each is its own partner
+                kb = 0;
                 self = true;
             }
         }
-        const int64_t kam = ka != 0 ? A - ka : 0, kbm = ka != 0 ? B - 1 - kb : (B - kb) % B;
+        const int64_t kam = ka != 0 ? A - ka : 0, kbm = self ? B / 2 : (ka != 0 ? B - 1 - kb : (B - kb) % B);
         const int64_t myka = side ? kam : ka, mykb = side ? kbm : kb;
-        const bool act = slot_ok && !(self && side);
+        const bool act = slot_ok;
         cf *row = Tm + (myka * B + mykb) * (int64_t)L;
         cf v[C::R];
 #pragma unroll
@@ -715,7 +742,7 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm
     static_assert(FftPlan<L>::LDS_ELEMS <= PER && 2 * FftPlan<L2>::LDS_ELEMS <= PER, "group region");
     lds = smem + grp * PER;
     cf *lds2 = lds + half * (PER / 2);
-    const int64_t AB = A * B, nslots = AB / 2 + 1;
+    const int64_t AB = A * B, nslots = AB / 2;                   // (one slot for the two self-mirrored rows, see k_hilbert_rowsmid)
     const int side = grp >= HP ? 1 : 0;
     const int pg = side ? grp - HP : grp;
     auto look = [&](const BigTw &bt, int64_t m) __attribute__((always_inline)) { return cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]); };
@@ -744,12 +771,12 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm
                 kb = s2 - (B / 2 - 1);
             } else {
                 ka = 0;
-                kb = s2 == B - 1 ? 0 : B / 2;
+                kb = 0;
                 self = true;
             }
         }
-        const int64_t kam = ka != 0 ? A - ka : 0, kbm = ka != 0 ? B - 1 - kb : (B - kb) % B;
-        return Slot{side ? kam : ka, side ? kbm : kb, slot_ok && !(self && side), self};
+        const int64_t kam = ka != 0 ? A - ka : 0, kbm = self ? B / 2 : (ka != 0 ? B - 1 - kb : (B - kb) % B);
+        return Slot{side ? kam : ka, side ? kbm : kb, slot_ok, self};
     };
     // the NEXT slot's rows are loaded while this one is transformed (SP_XCROWS_PREFETCH: the loop ran load -> two transforms -> store
     // with two workgroups per CU; no other workgroup writes a slot's rows, so the early read is safe)
