@@ -3,7 +3,7 @@
 namespace sp {
 
 int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf, BigTw bt) {
-    const int blocks = strided_blocks(xf.L, batch, c.ncu);
+    const int blocks = strided_blocks(xf.L, batch, c.ncu, xf.L == 4096 && !xf.blue ? 12 : 4);
 #define M_(XT)                                                                                        \
     hipLaunchKernelGGL((k_fft_c2c<XT>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, in, out, batch, \
                        inverse, xf.tb, bt);
@@ -200,7 +200,7 @@ int launch_hilbert_mid(LaunchCtx c, cf *Z, int64_t M, BigTw bt) {
 
 int launch_hilbert(LaunchCtx c, const float *x, int64_t n_in, int64_t x_ld, int64_t batch, const Xf &xf, cf *out,
                    const cf *H) {
-    const int blocks = strided_blocks(xf.L, batch, c.ncu);
+    const int blocks = strided_blocks(xf.L, batch, c.ncu, xf.L == 4096 && !xf.blue && !H ? 3 : 4);
 #define M_(XT)                                                                                        \
     if (H) hipLaunchKernelGGL((k_hilbert<XT, true>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n_in, \
                               x_ld, batch, xf.tb, out, H);                                            \

@@ -3590,10 +3590,16 @@ static __global__ void k_csdm_mirror(double *__restrict__ G, int nch, int nb, in
 #ifndef SP_HILBERT_WAVES
 #define SP_HILBERT_WAVES 1
 #endif
+#ifndef SP_HILBERT_EU
+#define SP_HILBERT_EU 3
+#endif
 // RESP: the spectrum is multiplied by the table H[0:n] instead of the mask (sp_spectral_filter: fft_deriv's
 // wavenumber, fft_analysis.py:1526-1546, or any other frequency response).
+// (the mask form takes 169 VGPRs unbounded -- one over what three workgroups of 256 threads per CU allow; held to 168)
 template <class X, bool RESP>
-__global__ __launch_bounds__(X::C::WG, SP_HILBERT_WAVES) void k_hilbert(const float *__restrict__ x, int64_t n_in, int64_t x_ld,
+__global__ __launch_bounds__(X::C::WG)
+    __attribute__((amdgpu_waves_per_eu((!RESP && X::C::WG == 256 && X::EXACT) ? SP_HILBERT_EU : SP_HILBERT_WAVES,
+                                       8))) void k_hilbert(const float *__restrict__ x, int64_t n_in, int64_t x_ld,
                                                        int64_t batch, XfTables tb, cf *__restrict__ out,
                                                        const cf *__restrict__ H) {
     SP_KERNEL_PROLOGUE(X)

@@ -79,14 +79,17 @@ inline RunPart run_partition_2d(int L, int64_t nframes, int ncu, int ny) {
 // 0.823; 8192 points: 0.245 / 0.170 / 0.160; 2048 points: 4 per CU wins for 4096 rows (0.039 vs 0.050), 16 for 65536 rows
 // (0.394 vs 0.413); <= 1024 points: no difference.  Rule: 4 per CU from 4096 points up; at 2048 points at least 4 rows per
 // workgroup (not below 2 per CU); 16 per CU otherwise.  SP_STRIDED_CAP overrides it.
-inline int strided_blocks(int L, int64_t items, int ncu) {
+// per_cu: the cap for L >= 4096 in workgroups per CU -- a multiple of what the kernel keeps resident per CU, so that the last
+// round of workgroups is a full one (round 3: k_fft_c2c<4096> holds 3 per CU; 4 per CU = 1024 workgroups ran 768 + a 256 tail:
+// 0.88 against 0.79 ms at 12 per CU for 65536 rows; the batched Hilbert, 4 rows per workgroup at 4096 rows: 0.065 -> 0.060 at 3)
+inline int strided_blocks(int L, int64_t items, int ncu, int per_cu = 4) {
     static const int forced = [] {
         const char *e = getenv("SP_STRIDED_CAP");
         return e ? atoi(e) : 0;
     }();
     const int fpw = fpw_of(L);
     int64_t b = (items + fpw - 1) / fpw;
-    int64_t cap = (int64_t)ncu * (forced > 0 ? forced : (L >= 4096 ? 4 : 16));
+    int64_t cap = (int64_t)ncu * (forced > 0 ? forced : (L >= 4096 ? per_cu : 16));
     if (forced <= 0 && L == 2048) {
         const int64_t q = b / 4;
         if (q < cap) cap = q > (int64_t)ncu * 2 ? q : (int64_t)ncu * 2;

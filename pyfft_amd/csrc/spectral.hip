@@ -1753,6 +1753,10 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
         const int64_t lm = long_chunk_frames(nfft, nframes);
         if (mc > lm) mc = lm;
     }
+    if (const char *e = getenv("SP_CSDM_CHUNK")) {               // experiment: frames per chunk (a multiple of 32)
+        const int64_t v = atoll(e) & ~(int64_t)31;
+        if (v >= 32 && v < mc) mc = v;
+    }
     if (mc > nframes) mc = nframes;
     // contraction on the matrix cores: fused form reading the STFT output as it lies (default), the form with a
     // transposed copy (SP_CSDM_TRANSPOSED=1), or the VALU kernel (SP_CSDM_VALU=1); the last two are kept for A/B tests
@@ -1781,7 +1785,8 @@ static int csd_matrix_impl(const char *who, const float *x, int nch, int64_t nsi
     cf *Xs = (cf *)g.cmS.p, *Xt = (cf *)g.cmT.p;
     // nfft 4096 at 50 % overlap: spectra by the pipeline of specialised waves (see below); m = frames of a chunk
     auto pipe_spec = [&](int64_t m) {
-        return use_bf16 && nfft == 4096 && 2 * hop == nfft && detrend != 2 && (m + 1) / 2 >= 32 * (int64_t)((g.ncu + nch - 1) / nch) &&
+        static const int64_t minp = getenv("SP_CSDM_MINPAIRS") ? atoll(getenv("SP_CSDM_MINPAIRS")) : 32;    // pairs per run
+        return use_bf16 && nfft == 4096 && 2 * hop == nfft && detrend != 2 && (m + 1) / 2 >= minp * (int64_t)((g.ncu + nch - 1) / nch) &&
                welch_pipe_wanted(xf, hop, (int64_t)1 << 40) && !env_flag("SP_CSDM_NOPIPESPEC");
     };
     // mean detrend in ONE pass over the signals (single chunk): the spectra stage subtracts an estimate mu0 of every channel's

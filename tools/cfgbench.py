@@ -39,6 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="cfg2,cfg3,cfg4,cfg5,hilbert,xcorr,cog")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--cfg5-detrend", type=int, default=1, help="0: cfg5 without the mean detrend (chunking experiments)")
     a = ap.parse_args()
     only = set(a.only.split(","))
     dev = torch.device("cuda", 0)
@@ -81,7 +82,8 @@ def main():
         x = torch.randn((nch, n), generator=g, device=dev, dtype=torch.float32)
         M = (n - nfft) // hop + 1
         win = windows("Hanning", nwins=nfft, verbose=False)
-        ms, G = timed(lambda: E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0), max(2, a.reps // 2))
+        dt = bool(a.cfg5_detrend)
+        ms, G = timed(lambda: E.csd_matrix(x, win, hop, M, detrend=dt, scale=1.0), max(2, a.reps // 2))
         flops = (nfft // 2 + 1) * nch * nch * 8.0 * M
         print("%-34s %9.3f ms  input %.0f GB/s, contraction %.1f TFLOP/s (of 157 fp32)  %8.1f Msamples/s" %
               ("cfg5 csd matrix 64ch x 2^24", ms, 4.0 * nch * n / ms / 1e6, flops / ms / 1e9, nch * n / ms / 1e3), flush=True)
@@ -89,7 +91,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(5):
-            E.csd_matrix(x, win, hop, M, detrend=True, scale=1.0)
+            E.csd_matrix(x, win, hop, M, detrend=dt, scale=1.0)
         torch.cuda.synchronize()
         print("%-34s %9.3f ms  per call" % ("cfg5 csd matrix, 5 back to back", (time.perf_counter() - t0) / 5 * 1e3), flush=True)
         ms, out = timed(lambda: E.welch_csd(x[0], x[1:], win, hop, M, detrend=True, sided=E.SIDED_ONE, scale=1.0), 2)
