@@ -226,7 +226,7 @@ int launch_fftfilt(LaunchCtx c, const float *x, int64_t n, int ntaps, const cf *
     }
 #define M_(XT)                                                                                        \
     if (pi1 > pi0) {                                                                                  \
-        const int blocks = strided_blocks(xf.L, pi1 - pi0, c.ncu);                                    \
+        const int blocks = strided_blocks(xf.L, pi1 - pi0, c.ncu, 6);      /* (three resident per CU) */ \
         hipLaunchKernelGGL((k_fftfilt<XT::L, false>), dim3(blocks), dim3(XT::C::WG), XT::C::lds_bytes(1), c.stream, x, n, \
                            ntaps, Hs, xf.tb, y, pi0, pi1);                                            \
     }                                                                                                 \

@@ -2821,8 +2821,11 @@ static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
 #ifndef SP_STFT_MINWAVES
 #define SP_STFT_MINWAVES 1
 #endif
+#ifndef SP_STFT_EU
+#define SP_STFT_EU SP_STFT_MINWAVES
+#endif
 template <int N, bool LIN, int SHIFT = 0>
-__global__ __launch_bounds__(WgCfg<N>::WG, SP_STFT_MINWAVES) void k_stft_rp(const float *__restrict__ x, const float *__restrict__ win,
+__global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu(SP_STFT_EU, 8))) void k_stft_rp(const float *__restrict__ x, const float *__restrict__ win,
                                                            int hop, int64_t nframes, int64_t ppg,
                                                            const float *__restrict__ trend, XfTables tb, int sided,
                                                            float amp, int out_power, void *__restrict__ out,
@@ -3651,8 +3654,18 @@ __global__ __launch_bounds__(X::C::WG)
 // Inputs of the next pair are loaded while the current pair is transformed.
 // ------------------------------------------------------------------------------------------
 // (launch bound: at least 2 waves per SIMD, i.e. <= 256 VGPRs -- unbounded, hipcc takes 264 and halves occupancy)
+// Round 3: the interior form at 2048 / 4096 points runs THREE workgroups per CU without the next pair's loads in flight (157-163
+// VGPRs) instead of two with them (208-215): cfg4 0.61-0.64 -> 0.53-0.58 ms on one box (tools/fir_ab.sh).  SP_FIR_EU=2
+// SP_FIR_PREFETCH=1 restore the old form.
+#ifndef SP_FIR_EU
+#define SP_FIR_EU 3
+#endif
+#ifndef SP_FIR_PREFETCH
+#define SP_FIR_PREFETCH 0
+#endif
 template <int N, bool EDGE>
-__global__ __launch_bounds__(WgCfg<N>::WG, 2) void k_fftfilt(const float *__restrict__ x, int64_t nsamp, int ntaps,
+__global__ __launch_bounds__(WgCfg<N>::WG)
+    __attribute__((amdgpu_waves_per_eu((!EDGE && WgCfg<N>::WG == 256 && N >= 2048) ? SP_FIR_EU : 2, 8))) void k_fftfilt(const float *__restrict__ x, int64_t nsamp, int ntaps,
                                                            const cf *__restrict__ Hs, XfTables tb,
                                                            float *__restrict__ y, int64_t p_begin, int64_t p_end) {
     using X = XfPow2<N>;
@@ -3681,16 +3694,21 @@ __global__ __launch_bounds__(WgCfg<N>::WG, 2) void k_fftfilt(const float *__rest
             }
         }
     };
+    constexpr bool PF = SP_FIR_PREFETCH || EDGE || WgCfg<N>::WG != 256 || N < 2048;
     cf nxt[C::R];
-    fetch(p_begin + (int64_t)blockIdx.x * C::FPW + grp, nxt);
+    if constexpr (PF) fetch(p_begin + (int64_t)blockIdx.x * C::FPW + grp, nxt);
     for (int64_t p0 = p_begin + (int64_t)blockIdx.x * C::FPW; p0 < p_end; p0 += stride) {
         const int64_t p = p0 + grp;
         const bool act = p < p_end;
         const int64_t s0 = 2 * p * Lb - P1, s1 = s0 + Lb;
         cf v[C::R];
+        if constexpr (PF) {
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) v[t] = nxt[t];
-        fetch(p + stride, nxt);
+            for (int t = 0; t < C::R; ++t) v[t] = nxt[t];
+            fetch(p + stride, nxt);
+        } else {
+            fetch(p, v);
+        }
         // the filter spectrum (32 KiB, L2-resident) is re-read every pair instead of pinning 32 VGPRs; the opaque
         // zero offset stops hipcc from hoisting the loads out of the loop and spilling
         int hoff = 0;
