@@ -71,6 +71,20 @@ int launch_pairspec(LaunchCtx c, const float *x, const float *win, int hop, int6
     return 0;
 }
 
+// workgroups of the selected k_welch_csd_pair instantiation one CU keeps resident (0: unknown)
+int csd_pair_resident(const Xf &xf, bool lin, bool onepass) {
+    if (onepass) return resident_per_cu((const void *)k_welch_csd_pair<4096, false, true>, WgCfg<4096>::WG, WgCfg<4096>::lds_bytes(1));
+#define CR_(NN)                                                                                       \
+    case NN:                                                                                          \
+        return lin ? resident_per_cu((const void *)k_welch_csd_pair<NN, true>, WgCfg<NN>::WG, WgCfg<NN>::lds_bytes(1)) \
+                   : resident_per_cu((const void *)k_welch_csd_pair<NN, false>, WgCfg<NN>::WG, WgCfg<NN>::lds_bytes(1));
+    switch (xf.L) {
+        CR_(32) CR_(64) CR_(128) CR_(256) CR_(512) CR_(1024) CR_(2048) CR_(4096) CR_(8192)
+        default: return 0;
+    }
+#undef CR_
+}
+
 int launch_csd_pair(LaunchCtx c, const float *y, int nch, int64_t y_ld, const float *win, int hop, int64_t nframes,
                     float *trend_y, bool lin, const Xf &xf, const cf *Zx, float *partial, const RunPart &rp, cf *spartial) {
     const int cf_ = (rp.blocks <= 65535 && !getenv("SP_CSD_RUNFAST")) ? 1 : 0;       // channel-fastest block order (grid.y <= 65535)

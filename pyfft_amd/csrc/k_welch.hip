@@ -1,5 +1,7 @@
 // k_welch.hip -- fused Welch PSD launchers (generic + register-carried metric kernel + one-pass detrend epilogue)
 #include "launch.h"
+#include <map>
+#include <mutex>
 namespace sp {
 
 bool welch_carry_eligible(const Xf &xf, int hop, bool lin) {
@@ -137,10 +139,49 @@ int launch_welch_finish(LaunchCtx c, const float *partial, int64_t G, const Xf &
     return 0;
 }
 
-// smallest power-of-two transform that uses the hinted entry point of k_welch_rp (experiments: -DSP_RP_HINT_MIN=...)
+// smallest power-of-two transform that uses the hinted entry point of k_welch_rp (experiments: -DSP_RP_HINT_MIN=...).
+// Round 3: 4096 (was 2048).  The round-1 finding "the 2-wave hint is 13 % faster at 2048 points" was an artefact of the run
+// partition: 4 groups per CU against the 3 workgroups the unhinted kernel keeps resident = a last round a third full.  With the
+// partition a multiple of the residency (welch_rp_groups_per_cu) the plain form wins: 0.281 -> 0.252 ms at 2^26 samples, nfft 2048,
+// 75 % overlap (tools/rp_ab.sh).
 #ifndef SP_RP_HINT_MIN
-#define SP_RP_HINT_MIN 2048
+#define SP_RP_HINT_MIN 4096
 #endif
+int resident_per_cu(const void *fn, int threads, size_t lds_bytes) {
+    struct Key {
+        const void *fn;
+        int threads;
+        size_t lds;
+        bool operator<(const Key &o) const { return fn != o.fn ? fn < o.fn : (threads != o.threads ? threads < o.threads : lds < o.lds); }
+    };
+    static std::mutex mu;
+    static std::map<Key, int> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    const Key k{fn, threads, lds_bytes};
+    auto it = cache.find(k);
+    if (it != cache.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, threads, lds_bytes) != hipSuccess || nb < 1) nb = 0;
+    cache[k] = nb;
+    return nb;
+}
+int welch_rp_groups_per_cu(const Xf &xf, bool lin) {
+    int res = 0;
+#define M_(XT)                                                                                        \
+    if constexpr (XT::EXACT && XT::L >= SP_RP_HINT_MIN) {                                             \
+        res = lin ? resident_per_cu((const void *)k_welch_rp<XT, true>, XT::C::WG, XT::C::lds_bytes(1))   \
+                  : resident_per_cu((const void *)k_welch_rp_h<XT, false>, XT::C::WG, XT::C::lds_bytes(1)); \
+    } else {                                                                                          \
+        res = lin ? resident_per_cu((const void *)k_welch_rp<XT, true>, XT::C::WG, XT::C::lds_bytes(1))   \
+                  : resident_per_cu((const void *)k_welch_rp<XT, false>, XT::C::WG, XT::C::lds_bytes(1)); \
+    }
+    SP_DISPATCH_X(xf, M_)
+#undef M_
+    // 1 or 2 resident: 4 per CU as before (whole rounds); 3: 3; more: one round
+    if (res <= 0) return default_groups_per_cu();
+    if (res <= 2) return 4;
+    return res > 8 ? 8 : res;
+}
 // real input, two frames per transform (power only); rp partitions PAIRS of frames
 int launch_welch_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
                     const Xf &xf, float *partial, const RunPart &rp) {

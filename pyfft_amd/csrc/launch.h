@@ -56,12 +56,25 @@ inline RunPart run_partition(int L, int64_t nframes, int ncu, int groups_per_cu 
 // the same for kernels whose grid has a second dimension of `ny` independent rows (channels): about 8 workgroups per
 // CU in total, so that the per-group partial spectra (ny x groups x 3..4 x L floats) stay small -- with 63 channels the
 // per-CU rule above wrote and re-read 1.6 GB of partials
-inline RunPart run_partition_2d(int L, int64_t nframes, int ncu, int ny) {
+// slots (optional) = workgroups the whole GPU keeps resident for this kernel: the group count per row is then rounded so that the
+// grid is just under a whole number of rounds (63 channels x 33 groups = 2079 workgroups over 512 slots ran a fifth round of 31;
+// 32 groups = 2016 run four: 2.51 -> 2.41 ms for the reference against 63 channels of 2^24 samples)
+inline RunPart run_partition_2d(int L, int64_t nframes, int ncu, int ny, int64_t slots = 0) {
     const int fpw = fpw_of(L);
     int64_t target = ((int64_t)ncu * 8 + ny - 1) / (ny > 0 ? ny : 1) * fpw;
     if (target < 8 * fpw) target = 8 * fpw;
     int64_t f = (nframes + target - 1) / target;
     if (f < 1) f = 1;
+    if (slots > 0 && ny > 0) {
+        const int64_t wg = ((nframes + f - 1) / f + fpw - 1) / fpw * ny;          // workgroups of the default rule
+        int64_t rounds = (wg + slots / 2) / slots;
+        if (rounds < 1) rounds = 1;
+        const int64_t groups = rounds * slots / ny * fpw;                          // groups per row that fill `rounds` rounds
+        if (groups >= 1) {
+            const int64_t f2 = (nframes + groups - 1) / groups;
+            if (f2 >= 1 && f2 <= 4 * f) f = f2;
+        }
+    }
     if (const char *e = getenv("SP_FPG")) {               // experiments: frames per group
         const int64_t v = atoll(e);
         if (v > 0) f = v;
@@ -98,6 +111,13 @@ inline int strided_blocks(int L, int64_t items, int ncu, int per_cu = 4) {
     if (b < 1) b = 1;
     return (int)b;
 }
+
+// workgroups of `fn` one CU keeps resident (registers, LDS, wave slots; asked once per kernel from the runtime): grids and run
+// partitions are sized as a multiple of it, so that the last round of workgroups is a full one
+int resident_per_cu(const void *fn, int threads, size_t lds_bytes);
+// groups per CU for k_welch_rp's run partition at this transform (a multiple of what the selected instantiation keeps resident)
+int welch_rp_groups_per_cu(const Xf &xf, bool lin);
+int csd_pair_resident(const Xf &xf, bool lin, bool onepass);
 
 // every launcher returns 0 or -1 (unsupported L); kernel launch errors surface through hipGetLastError
 int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf,

@@ -110,14 +110,15 @@ struct Pending {
     double *sum_d = nullptr;
 } g_pend;
 
-struct ProfScope {   // brackets one kernel launch with HIP events on the launch stream when profiling is on
+struct ProfScope {   // brackets one kernel launch with HIP events on its stream (default: the launch stream) when profiling is on
     bool on;
-    ProfScope() : on(g.profile) {
-        if (on) (void)hipEventRecord(g.ev0, g.stream);
+    hipStream_t st;
+    explicit ProfScope(hipStream_t s = nullptr) : on(g.profile), st(s ? s : g.stream) {
+        if (on) (void)hipEventRecord(g.ev0, st);
     }
     ~ProfScope() {
         if (on) {
-            (void)hipEventRecord(g.ev1, g.stream);
+            (void)hipEventRecord(g.ev1, st);
             g.prof_valid = true;
         }
     }
@@ -731,10 +732,15 @@ unsigned *get_ticket(Scratch &t) {
 }
 // streaming engine (sp_welch_dist_*): a scratch set of its own per step parity, and the epilogue launched on another stream
 // behind an event recorded after the main kernel -- so that it runs beside the NEXT step's main kernel
+// main / ev_in (optional): the main kernel goes to a lane of the engine's own instead of the launch stream, ordered behind an event
+// recorded on the launch stream just before it -- so that the NEXT step's main kernel (other lane) backfills the CUs as this
+// one's workgroups retire instead of waiting behind its last one
 struct SplitLaunch {
     Scratch *work, *onepass, *trend, *ticket;
     hipStream_t epi;
     hipEvent_t ev_main;
+    hipStream_t main = nullptr;
+    hipEvent_t ev_in = nullptr;
 };
 
 // want_sum: also produce the shard's plain sample sum (split ABI, one more tiny launch); without it the finish kernel
@@ -801,21 +807,28 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     const bool fused_ok = fo && !want_sum && !env_flag("SP_OP_UNFUSED") && cog_window_lobe(win, nfft, &lobe);
     const bool lobesum = fused_ok && pipe && !realpair && hop != nfft && !env_flag("SP_OP_NOLOBESUM") && window_cola(win, nfft, hop, &cola_c);
     if (!lobesum) cola_c = 0.0;
+    // the main kernel's stream: the launch stream, or the engine's lane behind everything enqueued on the launch stream so far
+    // (the caller's producer of x, the table uploads above, the wait for the epilogue that last used this scratch set)
+    const LaunchCtx mc = (sl && sl->main) ? LaunchCtx{sl->main, g.ncu} : lc();
+    if (sl && sl->main) {
+        HIPCHK(hipEventRecord(sl->ev_in, g.stream));
+        HIPCHK(hipStreamWaitEvent(sl->main, sl->ev_in, 0));
+    }
     if (pipe) {
-        ProfScope ps;
-        LAUNCHCHK(launch_welch_pipe(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, spartial,
+        ProfScope ps(mc.stream);
+        LAUNCHCHK(launch_welch_pipe(mc, xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, spartial,
                                     realpair ? 3 : (lobesum ? 9 : 0)));
         g.last_kernel = realpair ? "k_welch_pipe(onepass,realpair)" : (lobesum ? "k_welch_pipe(onepass,lobesum)" : "k_welch_pipe(onepass)");
     } else {
-        ProfScope ps;
-        LAUNCHCHK(launch_welch(lc(), xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,
+        ProfScope ps(mc.stream);
+        LAUNCHCHK(launch_welch(mc, xd, cplx, (const float *)win_d, hop, nframes, tb.f, false, xf, partial, rp, true,
                                spartial, &g.last_kernel));
     }
     if (!want_sum) st.dlt = nullptr;
     // the epilogue's launch context: the launch stream, or the engine's epilogue stream behind the main kernel's event
     LaunchCtx ec = lc();
     if (sl) {
-        HIPCHK(hipEventRecord(sl->ev_main, g.stream));
+        HIPCHK(hipEventRecord(sl->ev_main, mc.stream));
         HIPCHK(hipStreamWaitEvent(sl->epi, sl->ev_main, 0));
         ec = LaunchCtx{sl->epi, g.ncu};
     }
@@ -909,6 +922,10 @@ struct Comm {
 // kernels from two streams share the CUs when the first leaves registers and wave slots free; the main kernel takes 408 of a
 // SIMD's 512 VGPRs and 12 of a CU's 32 wave slots).  Only then does A wait for the PREVIOUS step's epilogue event -- which is
 // what makes that step's (without communicator) or the step before's (with) output valid for the caller, in stream order.
+// Round 3, later: the main kernels themselves go to two lanes of the engine's own (even / odd steps), each behind an event recorded
+// on A just before (A's history = the caller's producer of x + the waits for the epilogues that free the scratch set): consecutive
+// main kernels are then independent in the eyes of the hardware, and step k + 1's workgroups take the CUs as step k's retire -- no
+// launch gap, the pipeline fill of one kernel in the shadow of the other's drain.  x must stay valid until the step is reported.
 struct EngineSlot {
     bool busy = false;
     std::vector<float> win;
@@ -919,7 +936,8 @@ struct EngineSlot {
 };
 struct Engine {
     hipStream_t epi = nullptr;
-    hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_epi[2] = {nullptr, nullptr};
+    hipStream_t lane[2] = {nullptr, nullptr};          // main kernels of even / odd steps (SP_DIST_ONE_LANE=1: the launch stream)
+    hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_epi[2] = {nullptr, nullptr}, ev_in[2] = {nullptr, nullptr};
     Scratch work[2], onepass[2], trend[2], ticket[2], st[2];
     EngineSlot slot[2];
     int64_t nsub = 0;            // submits since the last flush
@@ -930,8 +948,10 @@ int engine_init() {
     if (geng.epi) return 0;
     HIPCHK(hipStreamCreateWithFlags(&geng.epi, hipStreamNonBlocking));
     for (int i = 0; i < 2; ++i) {
+        HIPCHK(hipStreamCreateWithFlags(&geng.lane[i], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&geng.ev_main[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&geng.ev_epi[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&geng.ev_in[i], hipEventDisableTiming));
     }
     return 0;
 }
@@ -939,9 +959,15 @@ void engine_release() {
     if (!geng.epi) return;
     (void)hipStreamSynchronize(geng.epi);
     for (int i = 0; i < 2; ++i) {
+        if (geng.lane[i]) {
+            (void)hipStreamSynchronize(geng.lane[i]);
+            (void)hipStreamDestroy(geng.lane[i]);
+            geng.lane[i] = nullptr;
+        }
         (void)hipEventDestroy(geng.ev_main[i]);
         (void)hipEventDestroy(geng.ev_epi[i]);
-        geng.ev_main[i] = geng.ev_epi[i] = nullptr;
+        if (geng.ev_in[i]) (void)hipEventDestroy(geng.ev_in[i]);
+        geng.ev_main[i] = geng.ev_epi[i] = geng.ev_in[i] = nullptr;
         geng.work[i].release();
         geng.onepass[i].release();
         geng.trend[i].release();
@@ -1238,7 +1264,9 @@ int sp_welch_psd(const void *x, int x_dtype, int64_t nsig, const float *win, int
         const bool pipe_rp = pair && detrend != 2 && allow_carry && 2 * hop == nfft && welch_pipe_wanted(xf, hop, (nframes + 1) / 2);
         const RunPart rp = pipe_rp ? run_partition(xf.L, (nframes + 1) / 2, g.ncu, welch_pipe_gpc())
                                    : (pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc())
-                                           : run_partition(xf.L, pair ? (nframes + 1) / 2 : nframes, g.ncu));
+                                           : (pair ? run_partition(xf.L, (nframes + 1) / 2, g.ncu,
+                                                                   getenv("SP_GROUPS_PER_CU") ? 0 : welch_rp_groups_per_cu(xf, detrend == 2))
+                                                   : run_partition(xf.L, nframes, g.ncu)));
         if (g.work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
         float *partial = (float *)g.work.p;
         {
@@ -1446,6 +1474,10 @@ int sp_welch_dist_submit(const void *x, int x_dtype, int64_t nsig, const float *
     // kernel of this step may overwrite its scratch set
     EngineSlot &cur = geng.slot[s], &prv = geng.slot[o];
     SplitLaunch sl{&geng.work[s], &geng.onepass[s], &geng.trend[s], &geng.ticket[s], geng.epi, geng.ev_main[s]};
+    if (!env_flag("SP_DIST_ONE_LANE")) {
+        sl.main = geng.lane[s];
+        sl.ev_in = geng.ev_in[s];
+    }
     const LaunchCtx ec{geng.epi, g.ncu};
     if (comm) {
         const size_t nst = 5 * (size_t)nfft + 8;
@@ -1632,7 +1664,7 @@ int sp_welch_csd(const void *x, const void *y, int dtype, int64_t nsig, int nch,
         // real x against many real channels: the reference's packed pair spectra once, then one transform per
         // (channel, frame PAIR); Pxx from the real-pair PSD kernel.  (SP_CSD_XIY=1: the x + i y_c form below.)
         const int64_t npairs = (nframes + 1) / 2;
-        const RunPart rpp = run_partition_2d(xf.L, npairs, g.ncu, nch);
+        const RunPart rpp = run_partition_2d(xf.L, npairs, g.ncu, nch, (int64_t)g.ncu * csd_pair_resident(xf, detrend == 2, pair_op));
         if (g.work.ensure(sizeof(float) * (size_t)rpp.groups * xf.L * 4 * (size_t)nch)) return -1;
         partial = (float *)g.work.p;
         if (g.cmS.ensure(sizeof(cf) * (size_t)npairs * (size_t)xf.L)) return -1;

@@ -104,3 +104,38 @@ def test_stream_error_paths_and_empty_flush():
         E.welch_dist_submit(x, np.hanning(1024), 512, 10, x.numel(), 5)           # frames_total < nframes
     assert E.welch_dist_flush() == 0
     assert E.comm_info() == (0, -1)
+
+
+@pytest.mark.parametrize("one_lane", [False, True])
+def test_main_kernel_lanes_follow_the_launch_stream(one_lane, monkeypatch):
+    """the main kernels run on two lanes of the engine's own (even / odd steps; SP_DIST_ONE_LANE=1: on the launch stream): every
+    step's input is PRODUCED on the launch stream right before its submit (a large torch kernel, no synchronisation), so a lane
+    that did not wait for the launch stream would read stale samples; twelve steps, each with its own mean and amplitude"""
+    import torch
+    from pyfft_amd import engine as E
+    from pyfft_amd.dist import NativeWelchPipeline
+    if one_lane:
+        monkeypatch.setenv("SP_DIST_ONE_LANE", "1")
+    nfft, hop, M = 4096, 2048, 6000
+    total = (M - 1) * hop + nfft
+    rng = np.random.default_rng(77)
+    base = (rng.standard_normal(total) + 1j * rng.standard_normal(total)).astype(np.complex64)
+    win = O.windows("Hanning", nwins=nfft)
+    ref0 = O.welch_psd_stream(base, win, nfft, hop, M, 1.0, detrend_style=1) * np.sum(win ** 2)     # detrended: the mean drops out
+    bd = torch.from_numpy(base).cuda()
+    pipe = NativeWelchPipeline(win, _plan(total, nfft, hop), scale=1.0, sided=E.SIDED_TWO)
+    bufs = [torch.zeros_like(bd) for _ in range(3)]
+    got, amps = [], []
+    for k in range(12):
+        a = 1.0 + 0.5 * k
+        amps.append(a)
+        buf = bufs[k % 3]                       # (a buffer is rewritten three submits later: its step was reported by then)
+        torch.mul(bd, a, out=buf)
+        buf += complex(0.3 * k, -0.1 * k)
+        r = pipe.submit(buf)
+        if r is not None:
+            got.append(r)
+    got += pipe.flush_all()
+    assert len(got) == 12
+    for g, a in zip(got, amps):
+        assert _excess(g.cpu().numpy(), a * a * ref0) <= 1.0, a
