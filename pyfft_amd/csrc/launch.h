@@ -46,6 +46,10 @@ inline RunPart run_partition(int L, int64_t nframes, int ncu, int groups_per_cu 
     const int64_t target = (int64_t)ncu * groups_per_cu * fpw;
     int64_t f = (nframes + target - 1) / target;
     if (f < 1) f = 1;
+    if (const char *e = getenv("SP_FPG1")) {              // experiments: frames per group of the one-dimensional partitions
+        const int64_t v = atoll(e);
+        if (v > 0) f = v;
+    }
     const int64_t G = (nframes + f - 1) / f;
     RunPart r;
     r.fpg = f;

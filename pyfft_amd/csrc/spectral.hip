@@ -19,7 +19,7 @@
 
 using namespace sp;
 
-#define SP_VERSION 105
+#define SP_VERSION 106
 #define SP_MAX_WG_FFT 8192
 #define SP_MAX_BIG_LOG2 26          /* longest multi-pass power-of-two transform: 2^26 points (512 MiB per buffer) */
 
