@@ -606,8 +606,14 @@ int get_window_spectrum(const float *win, int nfft, const Xf &xf, void **Wf_d) {
 }
 
 // the nfft-4096 Welch shapes run as a pipeline of specialised waves (k_welch_pipe.hip): one 768-thread workgroup per CU.
-// The pipeline spends 4 periods per workgroup filling and draining: taken from 32 frames per CU on; SP_WELCH_PIPE=0 turns it
-// off, 2 forces it for any frame count (the tests' way to reach its tail handling at small sizes).
+// The pipeline spends 4 periods per workgroup filling and draining; the symmetric kernel takes ~4 periods per frame and workgroup at
+// two workgroups per CU, so the pipeline wins from 2 frames per CU on (round 3, tools/minfpc_ab.sh, step / kernel ms: 2^24 samples
+// 0.054 / 0.045 against 0.071 / 0.060, 2^22: 0.045 / 0.024 against 0.062 / 0.036, 2^20: 0.038 / 0.019 against 0.053 / 0.020; the
+// threshold had been 32 per CU, which sent every shard below 2^25 samples to the symmetric kernel).  SP_PIPE_MINFPC sets the
+// threshold; SP_WELCH_PIPE=0 turns the pipeline off, 2 forces it for any frame count (the tests' way to reach its tail handling).
+#ifndef SP_PIPE_MINFPC_DEFAULT
+#define SP_PIPE_MINFPC_DEFAULT 2
+#endif
 static int welch_pipe_gpc() {
     static const int v = [] {
         const char *e = getenv("SP_PIPE_GPC");
@@ -625,7 +631,8 @@ static int welch_pipe_mode() {
 }
 static bool welch_pipe_wanted(const Xf &xf, int hop, int64_t nframes) {
     const int mode = welch_pipe_mode();
-    return welch_pipe_eligible(xf, hop) && (mode >= 2 || (mode == 1 && nframes >= 32 * (int64_t)g.ncu));
+    static const int64_t minfpc = getenv("SP_PIPE_MINFPC") ? atoll(getenv("SP_PIPE_MINFPC")) : SP_PIPE_MINFPC_DEFAULT;   // frames per CU
+    return welch_pipe_eligible(xf, hop) && (mode >= 2 || (mode == 1 && nframes >= minfpc * (int64_t)g.ncu - minfpc));
 }
 
 // FFT(window) on the host in float64, to find out whether it is confined to the bins ks = -K .. K, K <= 3 (periodic cosine-sum
@@ -922,10 +929,12 @@ struct Comm {
 // kernels from two streams share the CUs when the first leaves registers and wave slots free; the main kernel takes 408 of a
 // SIMD's 512 VGPRs and 12 of a CU's 32 wave slots).  Only then does A wait for the PREVIOUS step's epilogue event -- which is
 // what makes that step's (without communicator) or the step before's (with) output valid for the caller, in stream order.
-// Round 3, later: the main kernels themselves go to two lanes of the engine's own (even / odd steps), each behind an event recorded
-// on A just before (A's history = the caller's producer of x + the waits for the epilogues that free the scratch set): consecutive
-// main kernels are then independent in the eyes of the hardware, and step k + 1's workgroups take the CUs as step k's retire -- no
-// launch gap, the pipeline fill of one kernel in the shadow of the other's drain.  x must stay valid until the step is reported.
+// Round 3, later (opt-in, SP_DIST_TWO_LANES=1): the main kernels themselves go to two lanes of the engine's own (even / odd steps),
+// each behind an event recorded on A just before (A's history = the caller's producer of x + the waits for the epilogues that free
+// the scratch set): consecutive main kernels are then independent in the eyes of the hardware, and step k + 1's workgroups take
+// the CUs as step k's retire.  Measured +0.8 % per step -- and NOT the default: two main kernels that share the chip have no
+// duration of their own any more (rocprofv3 --kernel-trace reads 0.99 ms per launch instead of 0.54), which is what bench.py's
+// roofline figure and its rocprof cross-check are built on.  x must stay valid until the step is reported.
 struct EngineSlot {
     bool busy = false;
     std::vector<float> win;
@@ -936,7 +945,7 @@ struct EngineSlot {
 };
 struct Engine {
     hipStream_t epi = nullptr;
-    hipStream_t lane[2] = {nullptr, nullptr};          // main kernels of even / odd steps (SP_DIST_ONE_LANE=1: the launch stream)
+    hipStream_t lane[2] = {nullptr, nullptr};          // SP_DIST_TWO_LANES=1: main kernels of even / odd steps (default: the launch stream)
     hipEvent_t ev_main[2] = {nullptr, nullptr}, ev_epi[2] = {nullptr, nullptr}, ev_in[2] = {nullptr, nullptr};
     Scratch work[2], onepass[2], trend[2], ticket[2], st[2];
     EngineSlot slot[2];
@@ -1474,7 +1483,7 @@ int sp_welch_dist_submit(const void *x, int x_dtype, int64_t nsig, const float *
     // kernel of this step may overwrite its scratch set
     EngineSlot &cur = geng.slot[s], &prv = geng.slot[o];
     SplitLaunch sl{&geng.work[s], &geng.onepass[s], &geng.trend[s], &geng.ticket[s], geng.epi, geng.ev_main[s]};
-    if (!env_flag("SP_DIST_ONE_LANE")) {
+    if (env_flag("SP_DIST_TWO_LANES")) {          // opt-in (see the engine's comment): overlapping main kernels have no duration of their own
         sl.main = geng.lane[s];
         sl.ev_in = geng.ev_in[s];
     }

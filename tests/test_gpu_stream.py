@@ -106,16 +106,16 @@ def test_stream_error_paths_and_empty_flush():
     assert E.comm_info() == (0, -1)
 
 
-@pytest.mark.parametrize("one_lane", [False, True])
-def test_main_kernel_lanes_follow_the_launch_stream(one_lane, monkeypatch):
-    """the main kernels run on two lanes of the engine's own (even / odd steps; SP_DIST_ONE_LANE=1: on the launch stream): every
+@pytest.mark.parametrize("two_lanes", [False, True])
+def test_main_kernel_lanes_follow_the_launch_stream(two_lanes, monkeypatch):
+    """SP_DIST_TWO_LANES=1: the main kernels run on two lanes of the engine's own (even / odd steps) instead of the launch stream: every
     step's input is PRODUCED on the launch stream right before its submit (a large torch kernel, no synchronisation), so a lane
     that did not wait for the launch stream would read stale samples; twelve steps, each with its own mean and amplitude"""
     import torch
     from pyfft_amd import engine as E
     from pyfft_amd.dist import NativeWelchPipeline
-    if one_lane:
-        monkeypatch.setenv("SP_DIST_ONE_LANE", "1")
+    if two_lanes:
+        monkeypatch.setenv("SP_DIST_TWO_LANES", "1")
     nfft, hop, M = 4096, 2048, 6000
     total = (M - 1) * hop + nfft
     rng = np.random.default_rng(77)
