@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>          // types and enums only: the functions are resolved with dlsym (no link-time dependency)
 #include <dlfcn.h>
+#include <limits.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -774,6 +775,7 @@ struct SplitLaunch {
     hipEvent_t ev_main;
     hipStream_t main = nullptr;
     hipEvent_t ev_in = nullptr;
+    int reserve_cus = 0;       // CUs left to the collective's kernel: the main kernel is partitioned over ncu - reserve_cus
 };
 
 // want_sum: also produce the shard's plain sample sum (split ABI, one more tiny launch); without it the finish kernel
@@ -806,8 +808,9 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     //  runs at half the symmetric kernel's rate, 1.00 against 0.50 ms at 2^28 samples; the plain mode is faster there, 0.40 / 0.44)
     //  (SP_WELCH_PIPE=2 still forces it: tests/test_gpu_pipe.py keeps the instantiation correct)
     const bool pipe = realpair || ((hop != nfft || welch_pipe_mode() >= 2) && welch_pipe_wanted(xf, hop, nframes));
-    const RunPart rp = realpair ? run_partition(xf.L, (nframes + 1) / 2, g.ncu, welch_pipe_gpc())
-                                : (pipe ? run_partition(xf.L, nframes, g.ncu, welch_pipe_gpc()) : run_partition(xf.L, nframes, g.ncu));
+    const int ncu_p = (sl && sl->reserve_cus > 0 && sl->reserve_cus < g.ncu) ? g.ncu - sl->reserve_cus : g.ncu;   // (pipeline: one workgroup per CU)
+    const RunPart rp = realpair ? run_partition(xf.L, (nframes + 1) / 2, ncu_p, welch_pipe_gpc())
+                                : (pipe ? run_partition(xf.L, nframes, ncu_p, welch_pipe_gpc()) : run_partition(xf.L, nframes, g.ncu));
     if (S_work.ensure(sizeof(float) * (size_t)rp.groups * xf.L)) return -1;
     const size_t sp_bytes = sizeof(cf) * (size_t)rp.groups * (size_t)hop;
     const size_t st_doubles = (size_t)nfft + 2 * (size_t)hop + 8;
@@ -914,6 +917,7 @@ struct Rccl {
     void *dl = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitRankConfig)(ncclComm_t *, int, ncclUniqueId, int, void *) = nullptr;      // optional (NCCL >= 2.17)
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
@@ -928,6 +932,7 @@ int rccl_load() {
     if (!h) return fail("RCCL not found (librccl.so.1): %s", dlerror());
     *(void **)&rccl.GetUniqueId = dlsym(h, "ncclGetUniqueId");
     *(void **)&rccl.CommInitRank = dlsym(h, "ncclCommInitRank");
+    *(void **)&rccl.CommInitRankConfig = dlsym(h, "ncclCommInitRankConfig");
     *(void **)&rccl.CommDestroy = dlsym(h, "ncclCommDestroy");
     *(void **)&rccl.AllReduce = dlsym(h, "ncclAllReduce");
     *(void **)&rccl.GetErrorString = dlsym(h, "ncclGetErrorString");
@@ -945,7 +950,31 @@ int rccl_load() {
 struct Comm {
     ncclComm_t comm = nullptr;
     int world = 0, rank = -1;
+    int ctas = 0;              // workgroups the communicator's kernels were limited to (0: RCCL's own choice)
 } gcomm;
+
+// RCCL's collective kernel cannot run beside k_welch_pipe: rcclGenericKernel takes 261-280 VGPRs + 17-32 AGPRs per lane at 256
+// threads (code object metadata of librccl for gfx950) against the 80 per SIMD the pipeline leaves -- its workgroups would wait
+// for pipeline workgroups to retire and then hold back the NEXT main kernel's on those CUs for the collective's duration (all 256
+// workgroups of a main kernel are equal, so its makespan grows by that much).  Hence, with a communicator of more than one rank:
+// the communicator is created with at most SP_DIST_RCCL_CTAS workgroups (default 4: the state is 160 KiB, latency-bound) and the
+// streaming engine partitions its main kernels over ncu - that many CUs, so the collective always finds CUs of its own and
+// runs beside the main kernel like the light epilogue does.  SP_DIST_RESERVE_CUS overrides the number of CUs left free (also for
+// one rank, which is how the one-GPU tests reach the path), 0 turns it off.
+static int dist_rccl_ctas() {
+    const char *e = getenv("SP_DIST_RCCL_CTAS");
+    const int v = e ? atoi(e) : 4;
+    return v < 0 ? 0 : (v > 64 ? 64 : v);
+}
+static int dist_reserved_cus() {
+    if (const char *e = getenv("SP_DIST_RESERVE_CUS")) {
+        const int v = atoi(e);
+        return v < 0 ? 0 : (v > g.ncu / 2 ? g.ncu / 2 : v);
+    }
+    // (twice the workgroup limit, at least 8: a limit RCCL rounds up must still find room; 8 CUs cost 1.2-1.5 % of the main
+    //  kernel, tools/reserve_ab.sh: 0.5495 -> 0.5550 / 0.5580 ms at 2^28 samples for 4 / 8, 0.0819 -> 0.0825 / 0.0829 at 2^25)
+    return (gcomm.comm && gcomm.world > 1) ? (2 * gcomm.ctas > 8 ? 2 * gcomm.ctas : 8) : 0;
+}
 
 // ---- the streaming engine behind sp_welch_dist_submit / _flush ------------------------------------------------------------
 // Step k: the main kernel (k_welch_pipe / k_welch_carry) on the launch stream A into the scratch set of parity k & 1; an event;
@@ -1463,7 +1492,23 @@ int sp_comm_init(const void *id_in, int world, int rank) {
     HIPCHK(hipSetDevice(g.device));
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof id);
-    NCCLCHK(rccl.CommInitRank(&gcomm.comm, world, id, rank));
+    // at most `ctas` workgroups for this communicator's kernels (ncclConfig_t in its first public layout, NCCL 2.17: newer
+    // libraries accept the shorter structure by its size / version fields); without the entry point: RCCL's own choice
+    struct ConfigV217 {
+        size_t size;
+        unsigned magic, version;
+        int blocking, cgaClusterSize, minCTAs, maxCTAs;
+        const char *netName;
+    };
+    const int ctas = dist_rccl_ctas();
+    gcomm.ctas = 0;
+    if (rccl.CommInitRankConfig && ctas > 0) {
+        ConfigV217 cfg{sizeof(ConfigV217), 0xcafebeefu, 21700u, INT_MIN, INT_MIN, 1, ctas, nullptr};
+        NCCLCHK(rccl.CommInitRankConfig(&gcomm.comm, world, id, rank, &cfg));
+        gcomm.ctas = ctas;
+    } else {
+        NCCLCHK(rccl.CommInitRank(&gcomm.comm, world, id, rank));
+    }
     gcomm.world = world;
     gcomm.rank = rank;
     return 0;
@@ -1509,6 +1554,7 @@ int sp_welch_dist_submit(const void *x, int x_dtype, int64_t nsig, const float *
     // kernel of this step may overwrite its scratch set
     EngineSlot &cur = geng.slot[s], &prv = geng.slot[o];
     SplitLaunch sl{&geng.work[s], &geng.onepass[s], &geng.trend[s], &geng.ticket[s], geng.epi, geng.ev_main[s]};
+    sl.reserve_cus = comm ? dist_reserved_cus() : 0;
     if (env_flag("SP_DIST_TWO_LANES")) {          // opt-in (see the engine's comment): overlapping main kernels have no duration of their own
         sl.main = geng.lane[s];
         sl.ev_in = geng.ev_in[s];

@@ -122,6 +122,20 @@ def main():
         worst = max(worst, float(torch.max(torch.abs(g - one) / (2e-4 * torch.abs(one) + 1e-6 * one.max())).item()))
     out["native_pipeline_steps"] = len(got)
     out["native_pipeline_vs_single_call"] = worst
+    # the partition used with more than one rank: the main kernel over ncu - 4 CUs, the rest left to RCCL's kernel (which cannot
+    # run beside k_welch_pipe); forced here for the group of one rank
+    os.environ["SP_DIST_RESERVE_CUS"] = "4"
+    try:
+        rpipe = NativeWelchPipeline(win, plan, scale=1.0 / S2, sided=E.SIDED_TWO)
+        got = [r for r in (rpipe.submit(x) for x in xs) if r is not None] + rpipe.flush_all()
+    finally:
+        del os.environ["SP_DIST_RESERVE_CUS"]
+    worst = 0.0
+    for x, g in zip(xs, got):
+        one = E.welch_psd(x, win, hop, plan.frames, detrend=True, sided=E.SIDED_TWO, scale=1.0 / S2)
+        worst = max(worst, float(torch.max(torch.abs(g - one) / (2e-4 * torch.abs(one) + 1e-6 * one.max())).item()))
+    out["native_reserved_steps"] = len(got)
+    out["native_reserved_cus_vs_single_call"] = worst
     # a non-cosine-sum window (Kaiser): the epilogue takes the two-launch form (k_op_colsums + k_op_finish<EXPORT>)
     from pyfft_amd.windows import get_window
     wk = np.asarray(get_window(("kaiser", 8.0), nfft, fftbins=True), dtype=np.float64)

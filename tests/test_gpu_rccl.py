@@ -40,6 +40,8 @@ def test_rccl_world1_sharded_paths():
     assert d["native_pipeline_steps"] == 5
     assert d["native_pipeline_vs_single_call"] <= 1.0
     assert d["native_kaiser_vs_single_call"] <= 1.0
+    # main kernel partitioned over ncu - 4 CUs (what a communicator of more than one rank does: room for RCCL's kernel)
+    assert d["native_reserved_steps"] == 5 and d["native_reserved_cus_vs_single_call"] <= 1.0
 
 
 def test_bench_force_dist_world1():
