@@ -33,9 +33,16 @@ int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64
 #define RPS_(NN, S)                                                                                   \
     hipLaunchKernelGGL((k_stft_rp<NN, false, S>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
                        win, hop, nframes, rp.fpg, trend, xf.tb, sided, amp, out_power, out, pseg, x_cs, out_cs, out_ld)
+    // the one-sided complex spectrogram without per-frame power: compile-time form (k_stft_rp<.., FAST>)
+    const bool fast = !lin && sided == SIDED_ONE && out_power == 0 && pseg == nullptr && !getenv("SP_STFT_NOFAST");
+#define RPF_(NN, S)                                                                                   \
+    hipLaunchKernelGGL((k_stft_rp<NN, false, S, 1>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
+                       win, hop, nframes, rp.fpg, trend, xf.tb, sided, amp, out_power, out, pseg, x_cs, out_cs, out_ld)
 #define RPC_(NN)                                                                                      \
     case NN:                                                                                          \
-        if (shift == 4) RPS_(NN, 4);                                                                  \
+        if (fast && shift == 4) RPF_(NN, 4);                                                          \
+        else if (fast) RPF_(NN, 0);                                                                   \
+        else if (shift == 4) RPS_(NN, 4);                                                             \
         else if (lin) hipLaunchKernelGGL((k_stft_rp<NN, true>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG),     \
                                          WgCfg<NN>::lds_bytes(1), c.stream, x, win, hop, nframes, rp.fpg, trend, xf.tb, sided, \
                                          amp, out_power, out, pseg, x_cs, out_cs, out_ld);            \
@@ -57,6 +64,7 @@ int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64
 #undef RP_
 #undef RPC_
 #undef RPS_
+#undef RPF_
     return 0;
 }
 

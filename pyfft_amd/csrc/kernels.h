@@ -2824,8 +2824,16 @@ static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
 #ifndef SP_STFT_EU
 #define SP_STFT_EU SP_STFT_MINWAVES
 #endif
-template <int N, bool LIN, int SHIFT = 0>
-__global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu(SP_STFT_EU, 8))) void k_stft_rp(const float *__restrict__ x, const float *__restrict__ win,
+// (the FAST form at 1024 / 2048 points takes 174-183 VGPRs; held to 168 for three workgroups per CU, SP_STFT_FAST_EU=3, it spills
+//  6-13 registers and measured 0.40-0.46 ms against 0.32-0.34 at two per CU for cfg3, tools/stft_ab.sh: left at two)
+#ifndef SP_STFT_FAST_EU
+#define SP_STFT_FAST_EU SP_STFT_EU
+#endif
+// FAST = 1: the one-sided complex spectrogram without the per-frame time-domain power (sided == SIDED_ONE, out_power == 0, pseg ==
+// null: spectrogram.stft's shape, cfg3) as compile-time facts -- only the slots t < R/2 hold wanted bins (k < N/2), so half of the
+// mirror reads, of the X_a / X_b arithmetic and of the store addresses disappear, and so do the power sums.
+template <int N, bool LIN, int SHIFT = 0, int FAST = 0>
+__global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu((FAST && WgCfg<N>::WG == 256 && N <= 2048) ? SP_STFT_FAST_EU : SP_STFT_EU, 8))) void k_stft_rp(const float *__restrict__ x, const float *__restrict__ win,
                                                            int hop, int64_t nframes, int64_t ppg,
                                                            const float *__restrict__ trend, XfTables tb, int sided,
                                                            float amp, int out_power, void *__restrict__ out,
@@ -2912,11 +2920,13 @@ __global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu(SP
             const cf a = detrended<LIN>(mk(v[t].x, 0.f), tr, base_a + j);
             const cf b = detrended<LIN>(mk(v[t].y, 0.f), tr, base_b + j);
             v[t] = mk(w[t] * a.x, w[t] * b.x);
-            const float e = (j == 0 || j == N - 1) ? 0.5f : 1.f;
-            pwa += e * v[t].x * v[t].x;
-            pwb += e * v[t].y * v[t].y;
+            if constexpr (!FAST) {
+                const float e = (j == 0 || j == N - 1) ? 0.5f : 1.f;
+                pwa += e * v[t].x * v[t].x;
+                pwb += e * v[t].y * v[t].y;
+            }
         }
-        if (pseg != nullptr) {        // one atomic per wave and frame instead of one per thread
+        if (!FAST && pseg != nullptr) {        // one atomic per wave and frame instead of one per thread
             constexpr int W = C::T < 64 ? C::T : 64;
             pwa = group_lane_sum<W>(pwa);
             pwb = group_lane_sum<W>(pwb);
@@ -2931,7 +2941,21 @@ __global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu(SP
 #pragma unroll
         for (int t = 0; t < C::R; ++t) lds[tid + C::T * t] = v[t];
         __syncthreads();
-        if (act) {
+        if constexpr (FAST) {
+            if (act) {
+                cf *oa = reinterpret_cast<cf *>(out) + ga * nb + tid, *ob = oa + nb;
+                const float a2 = amp * 1.41421356237309504880f;
+#pragma unroll
+                for (int t = 0; t < C::R / 2; ++t) {                   // k = tid + T t < N/2: the one-sided bins, slot = k
+                    const int k = tid + C::T * t;
+                    const cf zm = lds[(N - k) & (N - 1)];
+                    const cf z = v[t];
+                    const float a = (k >= 1 && k <= N / 2 - 2) ? a2 : amp;             // [1:-1] of the cropped array is doubled
+                    st_stream(oa + C::T * t, mk(a * 0.5f * (z.x + zm.x), a * 0.5f * (z.y - zm.y)));
+                    if (has_b) st_stream(ob + C::T * t, mk(a * 0.5f * (z.y + zm.y), -a * 0.5f * (z.x - zm.x)));
+                }
+            }
+        } else if (act) {
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
                 const int k = tid + C::T * t;

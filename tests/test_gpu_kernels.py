@@ -644,6 +644,32 @@ def test_stft_golden_f32(E):
     np.testing.assert_allclose(P, g["Pxx"].real, rtol=2e-4, atol=1e-6 * g["Pxx"].real.max())
 
 
+@pytest.mark.parametrize("nfft,hop,M", [(2048, 512, 1001), (2048, 1024, 300), (1024, 256, 77), (4096, 1024, 64), (8192, 2048, 9)])
+def test_stft_one_sided_compile_time_form(E, nfft, hop, M):
+    """spectrogram.stft's shape (one-sided complex rows, no per-frame power) takes k_stft_rp<.., FAST>: the one-sided crop, the
+    doubling of [1:-1] and the store pattern as compile-time facts.  Against the generic form (SP_STFT_NOFAST=1) to rounding and
+    against the float64 frames (fft_analysis.py:2156-2203 restated); odd and even frame counts (a lone last frame), both the
+    register-carried (hop = nfft/4) and the plain fetch."""
+    import os
+    rng = np.random.default_rng(nfft + hop + M)
+    n = (M - 1) * hop + nfft + 3
+    x = (rng.standard_normal(n) + 0.3).astype(np.float32)
+    win = O.windows("Hanning", nwins=nfft)
+    X, _ = E.stft_frames(x, win, hop, M, detrend=True, sided=E.SIDED_ONE, amp_scale=0.5)
+    os.environ["SP_STFT_NOFAST"] = "1"
+    try:
+        X0, _ = E.stft_frames(x, win, hop, M, detrend=True, sided=E.SIDED_ONE, amp_scale=0.5)
+    finally:
+        del os.environ["SP_STFT_NOFAST"]
+    assert X.shape == X0.shape == (M, nfft // 2)
+    assert np.max(np.abs(X - X0)) <= 1e-6 * np.abs(X0).max()          # (same transform; the scale is applied in another order)
+    xd = x.astype(np.float64) - x.astype(np.float64).mean()
+    fr = np.stack([xd[g * hop: g * hop + nfft] * win for g in range(M)])
+    ref = np.fft.fft(fr, axis=1)[:, : nfft // 2] * 0.5
+    ref[:, 1:-1] *= np.sqrt(2.0)
+    assert np.max(np.abs(X - ref)) <= 1e-4 * np.abs(ref).max()
+
+
 def test_stft_twosided_complex_and_power_binmajor(E):
     g = load_golden("welch_class_c64_2e16_n4096")
     x = g["x"]
