@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Times the BASELINE.json configs 2-5 at full size on one MI355X (device-resident data, torch events on the
-current stream = the library's launch stream) and prints algorithmic GB/s per SURVEY.md section 8d.
+current stream = the library's launch stream) and prints algorithmic GB/s per SURVEY.md section 8d.  Round 3: the headline
+figure of a line is the SUSTAINED time per call (settled clocks, calls back to back); the isolated median of the earlier rounds
+follows in brackets (SP_CFGBENCH_ISOLATED=1: only that).
   python tools/cfgbench.py [--only cfg2,cfg3,...] [--reps 5]"""
 import argparse
 import os
@@ -15,7 +17,13 @@ from pyfft_amd import engine as E
 from pyfft_amd.windows import windows
 
 
+ISOLATED = {}      # name of the last timed() call's isolated median, printed by report()
+
+
 def timed(fn, reps):
+    """ms per call SUSTAINED: after ~30 ms of the same work (the clocks of this part settle only then: isolated calls with a host
+    wait in between read up to 30 % longer for the first dozen calls, tools/cog_series.py), `n` calls back to back between two
+    events, n chosen to fill ~20 ms.  The median of `reps` isolated calls (the figure of the earlier rounds) is kept in ISOLATED."""
     fn()
     torch.cuda.synchronize()
     ts = []
@@ -27,12 +35,28 @@ def timed(fn, reps):
         e1.record()
         torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    return float(np.median(ts)), out
+    iso = float(np.median(ts))
+    ISOLATED["last"] = iso
+    if os.environ.get("SP_CFGBENCH_ISOLATED", "0") == "1":
+        return iso, out
+    n = max(3, min(200, int(20.0 / max(iso, 1e-3))))
+    for _ in range(max(3, int(30.0 / max(iso, 1e-3)))):       # settle
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n, out
 
 
 def report(name, ms, alg_bytes, units, unit_name):
-    print("%-34s %9.3f ms  %8.0f GB/s alg (%4.1f%% of 8 TB/s)  %10.1f M%s/s" %
-          (name, ms, alg_bytes / ms / 1e6, 100 * alg_bytes / ms / 1e6 / 8000, units / ms / 1e3, unit_name), flush=True)
+    print("%-34s %9.3f ms  %8.0f GB/s alg (%4.1f%% of 8 TB/s)  %10.1f M%s/s   [isolated median %.3f ms]" %
+          (name, ms, alg_bytes / ms / 1e6, 100 * alg_bytes / ms / 1e6 / 8000, units / ms / 1e3, unit_name, ISOLATED.get("last", float("nan"))),
+          flush=True)
 
 
 def main():
@@ -85,8 +109,8 @@ def main():
         dt = bool(a.cfg5_detrend)
         ms, G = timed(lambda: E.csd_matrix(x, win, hop, M, detrend=dt, scale=1.0), max(2, a.reps // 2))
         flops = (nfft // 2 + 1) * nch * nch * 8.0 * M
-        print("%-34s %9.3f ms  input %.0f GB/s, contraction %.1f TFLOP/s (of 157 fp32)  %8.1f Msamples/s" %
-              ("cfg5 csd matrix 64ch x 2^24", ms, 4.0 * nch * n / ms / 1e6, flops / ms / 1e9, nch * n / ms / 1e3), flush=True)
+        print("%-34s %9.3f ms  input %.0f GB/s, contraction %.1f TFLOP/s (of 157 fp32)  %8.1f Msamples/s   [isolated median %.3f ms]" %
+              ("cfg5 csd matrix 64ch x 2^24", ms, 4.0 * nch * n / ms / 1e6, flops / ms / 1e9, nch * n / ms / 1e3, ISOLATED.get("last", float("nan"))), flush=True)
         # the same call 5 times back to back (no idle gap between the calls: clocks stay up), mean per call
         torch.cuda.synchronize()
         t0 = time.perf_counter()
