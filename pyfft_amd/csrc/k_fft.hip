@@ -273,6 +273,16 @@ int launch_moments(LaunchCtx c, const void *x, bool cplx, int64_t n, int mode, d
     return 0;
 }
 
+// ccf: means / sums of squares of two real signals (x_cs samples apart) and the normalisation record xc_out[4] in two launches
+int launch_moments_xc(LaunchCtx c, const float *x, int64_t n, double *partial, double *out_d, double *xc_out, int64_t x_cs) {
+    int64_t nb = (n + 256 * 16 - 1) / (256 * 16);
+    if (nb > 2048) nb = 2048;
+    if (nb < 1) nb = 1;
+    hipLaunchKernelGGL((k_moments_partial<false, false>), dim3((unsigned)nb, 2), dim3(256), 0, c.stream, x, n, partial, x_cs);
+    hipLaunchKernelGGL(k_moments_finish_xc, dim3(1), dim3(256), 0, c.stream, partial, (int)nb, n, out_d, xc_out);
+    return 0;
+}
+
 int launch_transpose(LaunchCtx c, const void *in, void *out, int64_t rows, int64_t cols, int elem_bytes) {
     dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
     if (elem_bytes == 4)

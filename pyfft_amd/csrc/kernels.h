@@ -3956,4 +3956,47 @@ static __global__ __launch_bounds__(256) void k_moments_finish(const double *__r
     }
 }
 
+// ccf (ccf.py:74-76): both signals' moment records finished by ONE block and the normalisation record [mean1, mean2, 1 / (n std1
+// std2), 0] written behind them -- k_moments_finish x2 + k_xcorr_norm in one launch (two kernel boundaries less per call)
+static __global__ __launch_bounds__(256) void k_moments_finish_xc(const double *__restrict__ partial, int nblocks, int64_t n,
+                                                            double *__restrict__ out_d, double *__restrict__ xc_out) {
+    __shared__ double sh[3][256];
+    double mean[2], ssq[2];
+    for (int sig = 0; sig < 2; ++sig) {
+        const double *pp = partial + (int64_t)sig * nblocks * 8;
+        double s0 = 0, s2 = 0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) {
+            s0 += pp[b * 8 + 0];
+            s2 += pp[b * 8 + 2];
+        }
+        sh[0][threadIdx.x] = s0;
+        sh[2][threadIdx.x] = s2;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) {
+                sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+                sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
+            }
+            __syncthreads();
+        }
+        mean[sig] = sh[0][0] / (double)n;
+        ssq[sig] = sh[2][0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        for (int sig = 0; sig < 2; ++sig) {
+            out_d[sig * 8 + 0] = mean[sig];
+            out_d[sig * 8 + 1] = 0.0;
+            out_d[sig * 8 + 2] = ssq[sig];
+            out_d[sig * 8 + 3] = 0.0;
+            out_d[sig * 8 + 4] = 0.0;
+        }
+        const double v1 = ssq[0] / (double)n - mean[0] * mean[0], v2 = ssq[1] / (double)n - mean[1] * mean[1];
+        xc_out[0] = mean[0];
+        xc_out[1] = mean[1];
+        xc_out[2] = 1.0 / ((double)n * sqrt(v1 > 0 ? v1 : 0) * sqrt(v2 > 0 ? v2 : 0));
+        xc_out[3] = 0;
+    }
+}
+
 }   // namespace sp

@@ -231,6 +231,7 @@ int launch_fftfilt(LaunchCtx c, const float *x, int64_t n, int ntaps, const cf *
 int launch_xcorr(LaunchCtx c, const float *x1, const float *x2, int64_t n, const double *mom, const Xf &xf, float *co);
 int launch_moments(LaunchCtx c, const void *x, bool cplx, int64_t n, int mode, double *partial_scratch, double *out_d,
                    float *trend_f, int nsignals = 1, int64_t x_cs = 0);
+int launch_moments_xc(LaunchCtx c, const float *x, int64_t n, double *partial, double *out_d, double *xc_out, int64_t x_cs);
 int launch_transpose(LaunchCtx c, const void *in, void *out, int64_t rows, int64_t cols, int elem_bytes);
 // segments longer than one workgroup transform (k_long.hip); m frames starting at frame f0, rows S[m][nfft]
 int launch_long_segstats(LaunchCtx c, const void *x, bool cplx, int64_t f0, int64_t m, int hop, int nfft, int mode, float *rec);

@@ -2468,8 +2468,8 @@ int sp_xcorr(const float *x1, const float *x2, int64_t n, float *co_out, int mem
     if (!scr) return -1;
     // both signals' mean / variance in ONE pair of launches (two "channels" b - a samples apart: any two device rows; each
     // signal's own pass cost 21 + 8 us of the long ccf's 0.9 ms)
-    LAUNCHCHK(launch_moments(lc(), a, false, n, 1, scr, tb.d, nullptr, 2, (int64_t)(b - a)));
-    hipLaunchKernelGGL(k_xcorr_norm, dim3(1), dim3(64), 0, g.stream, tb.d, tb.d + 8, n, tb.d + 16);
+    // (and the normalisation record behind them: one finish launch for both signals, no k_xcorr_norm)
+    LAUNCHCHK(launch_moments_xc(lc(), a, n, scr, tb.d, tb.d + 16, (int64_t)(b - a)));
     if (L <= SP_MAX_WG_FFT) {
         Xf xf;
         if (get_xf(L, &xf)) return -1;
