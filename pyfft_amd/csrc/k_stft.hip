@@ -23,6 +23,26 @@ int launch_stft(LaunchCtx c, const void *x, bool cplx, const float *win, int hop
 }
 
 // real input, power-of-two n >= 32: two frames per transform; rp partitions PAIRS of frames
+// groups per CU for k_stft_rp's run partition: twice what the selected instantiation keeps resident when that is three or more
+// (the compile-time one-sided form with the window in LDS), else the default 4 (one or two resident: whole rounds)
+int stft_rp_groups_per_cu(const Xf &xf, bool lin, int hop, int sided, int out_power, bool pseg) {
+    if (xf.blue || lin || !(sided == SIDED_ONE && out_power == 0 && !pseg) || getenv("SP_STFT_NOFAST") || getenv("SP_GROUPS_PER_CU")) return 0;
+    const int T_ = xf.L / 16;
+    const bool s4 = xf.L >= 1024 && hop % T_ == 0 && hop / T_ == 4 && !getenv("SP_STFT_NOCARRY");
+    int res = 0;
+#define RQ_(NN)                                                                                       \
+    case NN:                                                                                          \
+        res = s4 ? resident_per_cu((const void *)k_stft_rp<NN, false, 4, 1>, WgCfg<NN>::WG, WgCfg<NN>::lds_bytes(1) + (SP_STFT_WLDS ? sizeof(float) * NN : 0)) \
+                 : resident_per_cu((const void *)k_stft_rp<NN, false, 0, 1>, WgCfg<NN>::WG, WgCfg<NN>::lds_bytes(1) + (SP_STFT_WLDS ? sizeof(float) * NN : 0)); \
+        break;
+    switch (xf.L) {
+        RQ_(1024) RQ_(2048) RQ_(4096) RQ_(8192)
+        default: return 0;
+    }
+#undef RQ_
+    return res >= 3 ? 2 * res : 0;
+}
+
 int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64_t nframes, const float *trend, bool lin,
                    const Xf &xf, const RunPart &rp, int sided, float amp, int out_power, void *out, double *pseg, int nchan,
                    int64_t x_cs, int64_t out_cs, int out_ld) {
@@ -36,7 +56,8 @@ int launch_stft_rp(LaunchCtx c, const float *x, const float *win, int hop, int64
     // the one-sided complex spectrogram without per-frame power: compile-time form (k_stft_rp<.., FAST>)
     const bool fast = !lin && sided == SIDED_ONE && out_power == 0 && pseg == nullptr && !getenv("SP_STFT_NOFAST");
 #define RPF_(NN, S)                                                                                   \
-    hipLaunchKernelGGL((k_stft_rp<NN, false, S, 1>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG), WgCfg<NN>::lds_bytes(1), c.stream, x, \
+    hipLaunchKernelGGL((k_stft_rp<NN, false, S, 1>), dim3(rp.blocks, nchan), dim3(WgCfg<NN>::WG),     \
+                       WgCfg<NN>::lds_bytes(1) + (SP_STFT_WLDS ? sizeof(float) * NN : 0), c.stream, x,    \
                        win, hop, nframes, rp.fpg, trend, xf.tb, sided, amp, out_power, out, pseg, x_cs, out_cs, out_ld)
 #define RPC_(NN)                                                                                      \
     case NN:                                                                                          \

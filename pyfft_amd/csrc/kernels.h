@@ -2824,10 +2824,15 @@ static __global__ __launch_bounds__(LIGHT ? SP_OPF_WG_LIGHT : SP_OPF_WG)
 #ifndef SP_STFT_EU
 #define SP_STFT_EU SP_STFT_MINWAVES
 #endif
-// (the FAST form at 1024 / 2048 points takes 174-183 VGPRs; held to 168 for three workgroups per CU, SP_STFT_FAST_EU=3, it spills
-//  6-13 registers and measured 0.40-0.46 ms against 0.32-0.34 at two per CU for cfg3, tools/stft_ab.sh: left at two)
+// (the FAST form at 1024 / 2048 points takes 174-183 VGPRs with the window in registers; held to 168 for three workgroups per CU,
+//  SP_STFT_FAST_EU=3, it spills 6-13 registers and measured 0.40-0.46 ms against 0.32-0.34 at two per CU for cfg3, tools/stft_ab.sh.
+//  With the window in LDS (SP_STFT_WLDS, the default) it takes 155-163 and runs three per CU unforced: 0.282 -> 0.275 ms sustained,
+//  0.318 -> 0.296 isolated, tools/stftw_ab.sh)
 #ifndef SP_STFT_FAST_EU
 #define SP_STFT_FAST_EU SP_STFT_EU
+#endif
+#ifndef SP_STFT_WLDS
+#define SP_STFT_WLDS 1          // FAST form: window in LDS (158 VGPRs, three workgroups per CU; 0: in registers, 178, two)
 #endif
 // FAST = 1: the one-sided complex spectrogram without the per-frame time-domain power (sided == SIDED_ONE, out_power == 0, pseg ==
 // null: spectrogram.stft's shape, cfg3) as compile-time facts -- only the slots t < R/2 hold wanted bins (k < N/2), so half of the
@@ -2841,9 +2846,23 @@ __global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu((F
                                                            int out_ld /* row pitch of `out` in elements; 0: nbins */) {
     using X = XfPow2<N>;
     SP_KERNEL_PROLOGUE(X)
-    float w[C::R];
+    // SP_STFT_WLDS (FAST form): the window lives in LDS behind the transform images, [q][thread] float4 = slots 4q .. 4q + 3 of a
+    // thread (conflict-free 16-byte reads), instead of 16 registers -- what the form lacks to fit three workgroups per CU
+    constexpr bool WLDS = FAST && SP_STFT_WLDS;
+    float w[WLDS ? 1 : C::R];
+    float4 *w4 = reinterpret_cast<float4 *>(smem + C::FPW * C::LDS_PER);
+    if constexpr (WLDS) {
+        if (grp == 0) {
 #pragma unroll
-    for (int t = 0; t < C::R; ++t) w[t] = win[tid + C::T * t];
+            for (int q = 0; q < C::R / 4; ++q)
+                w4[q * C::T + tid] = make_float4(win[tid + C::T * (4 * q)], win[tid + C::T * (4 * q + 1)], win[tid + C::T * (4 * q + 2)],
+                                                 win[tid + C::T * (4 * q + 3)]);
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int t = 0; t < C::R; ++t) w[t] = win[tid + C::T * t];
+    }
     x += (int64_t)blockIdx.y * x_cs;
     // out_power 0: complex rows [frame][bin]; 1: float power; 2: complex, the two frames of a pair side by side and the
     // (<= 64) channels interleaved per group of 8 bins, [pair][bin group][channel][8][2] (one 16-byte store per bin; the layout
@@ -2919,7 +2938,14 @@ __global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu((F
             const int j = tid + C::T * t;
             const cf a = detrended<LIN>(mk(v[t].x, 0.f), tr, base_a + j);
             const cf b = detrended<LIN>(mk(v[t].y, 0.f), tr, base_b + j);
-            v[t] = mk(w[t] * a.x, w[t] * b.x);
+            float wt;
+            if constexpr (WLDS) {
+                const float4 wq = w4[(t / 4) * C::T + tid];
+                wt = (t % 4) == 0 ? wq.x : ((t % 4) == 1 ? wq.y : ((t % 4) == 2 ? wq.z : wq.w));
+            } else {
+                wt = w[t];
+            }
+            v[t] = mk(wt * a.x, wt * b.x);
             if constexpr (!FAST) {
                 const float e = (j == 0 || j == N - 1) ? 0.5f : 1.f;
                 pwa += e * v[t].x * v[t].x;

@@ -122,6 +122,7 @@ int resident_per_cu(const void *fn, int threads, size_t lds_bytes);
 // groups per CU for k_welch_rp's run partition at this transform (a multiple of what the selected instantiation keeps resident)
 int welch_rp_groups_per_cu(const Xf &xf, bool lin);
 int csd_pair_resident(const Xf &xf, bool lin, bool onepass);
+int stft_rp_groups_per_cu(const Xf &xf, bool lin, int hop, int sided, int out_power, bool pseg);
 
 // every launcher returns 0 or -1 (unsupported L); kernel launch errors surface through hipGetLastError
 int launch_fft_c2c(LaunchCtx c, const cf *in, cf *out, int64_t batch, int inverse, const Xf &xf,

@@ -2120,7 +2120,8 @@ int sp_stft(const void *x, int x_dtype, int64_t nsig, const float *win, int nfft
             LAUNCHCHK(launch_long_stft_out(lc(), S, m, nfft, sided, (float)amp_scale, out_kind, fm, f0, (int)nb));
         }
     } else if (pair) {
-        const RunPart rp = run_partition(xf.L, (nframes + 1) / 2, g.ncu);
+        const RunPart rp = run_partition(xf.L, (nframes + 1) / 2, g.ncu,
+                                         stft_rp_groups_per_cu(xf, detrend == 2, hop, sided, out_kind, pseg_d != nullptr));
         LAUNCHCHK(launch_stft_rp(lc(), (const float *)xd, (const float *)win_d, hop, nframes, tb.f, detrend == 2, xf, rp, sided,
                                  (float)amp_scale, out_kind, fm, pseg_d));
     } else {
