@@ -108,7 +108,7 @@ int launch_fft_rows_rev(LaunchCtx c, const cf *in, cf *out, int64_t A, int64_t B
     return 0;
 }
 
-int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, BigTw btN) {
+int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, BigTw btN, const cf *tw2c) {
     if (xc.blue || A < 2 || B < 2) return -1;
     const int64_t nslots = A * B / 2;
 #define RM_(LL)                                                                                        \
@@ -116,7 +116,7 @@ int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &
         constexpr int HP = WgCfg<LL>::FPW / 2;                                                        \
         const int64_t iters = (nslots + HP - 1) / HP, cap = (int64_t)c.ncu * 4;                       \
         hipLaunchKernelGGL((k_hilbert_rowsmid<LL>), dim3((unsigned)(iters < cap ? iters : cap)), dim3(WgCfg<LL>::WG),   \
-                           WgCfg<LL>::lds_bytes(1), c.stream, Tm, A, B, xc.tb, btN);                  \
+                           WgCfg<LL>::lds_bytes(1), c.stream, Tm, A, B, xc.tb, btN, tw2c);            \
         return 0;                                                                                     \
     }
     switch (xc.L) {

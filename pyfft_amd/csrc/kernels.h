@@ -636,7 +636,8 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_fft_rows_rev(const cf *__restr
 // (4 x 64 MB of the 960 MB a 2^24-sample Hilbert moved; 7 launches -> 5).  k_fft_cols_inv are the two adjoint column passes:
 // the inter-pass twiddle (conjugate) BEFORE the transform; the last one writes the analytic signal.
 template <int L>
-__global__ __launch_bounds__(WgCfg<L>::WG) void k_hilbert_rowsmid(cf *__restrict__ Tm, int64_t A, int64_t B, XfTables tb, BigTw btN) {
+__global__ __launch_bounds__(WgCfg<L>::WG) void k_hilbert_rowsmid(cf *__restrict__ Tm, int64_t A, int64_t B, XfTables tb, BigTw btN,
+                                                               const cf *__restrict__ tw2c /* exp(-2 pi i m / (2 C)), m < 2 C */) {
     using X = XfPow2<L>;
     SP_KERNEL_PROLOGUE(X)
     (void)n;
@@ -693,10 +694,13 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_hilbert_rowsmid(cf *__restrict
             b[t] = pl[zero_row ? ((L - kc) & (L - 1)) : (L - 1 - kc)];
         }
         __syncthreads();                                         // the images are free for the next transform
+        // W_N^k = W_N^{ka + A kb} W_{2C}^{kc} (N = 2 A B C): one two-level look-up per row, the rest from the (2 C)-point twiddle
+        // table (L1-resident) -- instead of sixteen scattered two-level look-ups per thread
+        const cf w0 = look(myka + A * mykb);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int64_t k = myka + A * (mykb + B * (int64_t)(tid + C::T * t));
-            const cf w = look(k);                                // W_N^k, N = 2 M
+            const cf w = cmul(w0, tw2c[tid + C::T * t]);         // W_N^k, N = 2 M
             const cf a = v[t], bb = b[t];
             const cf p = mk(a.x + bb.x, a.y - bb.y), q = mk(a.x - bb.x, a.y + bb.y);          // a + conj b, a - conj b
             const cf r = cmul(cconj(w), p) - cmul(w, q);

@@ -216,7 +216,7 @@ int launch_cog_finish_op(LaunchCtx c, const cf *acc, int wpf, int64_t nframes, d
 int launch_csdm_fused(LaunchCtx c, const cf *Xs, cf *Xt_tail, int nch, int64_t m, int nb, double *G, int ld = 0);
 int launch_hilbert_mid(LaunchCtx c, cf *Z, int64_t M, BigTw bt);
 // half-length Hilbert with the middle step inside the row pass + the two adjoint column passes (k_hilbert_rowsmid, k_fft_cols_inv)
-int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, BigTw btN);
+int launch_hilbert_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, BigTw btN, const cf *tw2c);
 // long ccf with the middle step and the half-length transform's first pass inside the row pass (k_xc_rowsmid, k_fft_cols_lag)
 int launch_xc_rowsmid(LaunchCtx c, cf *Tm, int64_t A, int64_t B, const Xf &xc, const Xf &xc2, BigTw btL, BigTw btM);
 int launch_fft_cols_lag(LaunchCtx c, const cf *in, int64_t ncols, int64_t nouter, int64_t es, int64_t os, const Xf &xf, RowsOut ro);

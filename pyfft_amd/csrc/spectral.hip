@@ -2301,6 +2301,8 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
                     Xf xa, xb, xc;
                     BigTw btM;
                     if (get_xf(Aa, &xa) || get_xf(Bb, &xb) || get_xf(Cc, &xc) || get_bigtw(Mh, &btM)) return -1;
+                    const cf *tw2c = nullptr;                     // exp(-2 pi i m / (2 C)): the row pass's share of W_N^k
+                    if (get_twiddles(2 * Cc, &tw2c)) return -1;
                     if (Aa >= 64 && Bb >= 64 && Cc >= 32 && Cc <= 2048) {
                         // (a full, 8-byte aligned row IS the complex sequence z: the plain first pass at three workgroups per CU
                         //  instead of the predicated pair load at two -- 58 -> 38 us at 2^24 samples)
@@ -2310,7 +2312,7 @@ int sp_hilbert(const float *x, int64_t n_in, int64_t x_ld, int64_t nfft, int64_t
                             LAUNCHCHK(launch_fft_cols(lc(), A, A, Bb * Cc, 1, Bb * Cc, 0, 1, 0, xa, btM, 0, fz.ci));
                         }
                         LAUNCHCHK(launch_fft_cols(lc(), A, A, Cc, Aa, Cc, Bb * Cc, Aa, 0, xb, btM));
-                        LAUNCHCHK(launch_hilbert_rowsmid(lc(), A, Aa, Bb, xc, btN));
+                        LAUNCHCHK(launch_hilbert_rowsmid(lc(), A, Aa, Bb, xc, btN, tw2c));
                         LAUNCHCHK(launch_fft_cols_inv(lc(), A, A, Cc, Aa, Cc, Bb * Cc, Aa, xb, btM, 1.f, nullptr));
                         RowsOut ao;
                         ao.co = reinterpret_cast<float *>(od + b * nfft);
