@@ -649,31 +649,33 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_hilbert_rowsmid(cf *__restrict
     const int side = grp >= HP ? 1 : 0;
     const int pg = side ? grp - HP : grp;
     auto look = [&](int64_t m) __attribute__((always_inline)) { return cmul(btN.hi[m >> btN.lb], btN.lo[m & ((1 << btN.lb) - 1)]); };
-    for (int64_t s0 = (int64_t)blockIdx.x * HP; s0 < nslots; s0 += (int64_t)gridDim.x * HP) {
-        const int64_t s = s0 + pg;
-        const bool slot_ok = s < nslots;
-        const int64_t sc = slot_ok ? s : 0;
-        int64_t ka, kb;
+    // (slot arithmetic in 32 bits with shifts: A, B are powers of two and A B <= 2^16 -- the 64-bit divisions cost registers and time)
+    const int Ai = (int)A, Bi = (int)B, lbB = __ffs(Bi) - 1, ABh = (int)(AB / 2), nsl = (int)nslots;
+    for (int s0 = (int)blockIdx.x * HP; s0 < nsl; s0 += (int)gridDim.x * HP) {
+        const int s = s0 + pg;
+        const bool slot_ok = s < nsl;
+        const int sc = slot_ok ? s : 0;
+        int ka, kb;
         bool self = false;
-        if (sc < AB / 2 - B) {                                   // rows with 1 <= ka < A/2 (mirror: A/2 < ka' <= A - 1)
-            const int64_t j = B + sc;
-            ka = j / B;
-            kb = j % B;
+        if (sc < ABh - Bi) {                                     // rows with 1 <= ka < A/2 (mirror: A/2 < ka' <= A - 1)
+            const int j = Bi + sc;
+            ka = j >> lbB;
+            kb = j & (Bi - 1);
         } else {
-            const int64_t s2 = sc - (AB / 2 - B);
-            if (s2 < B / 2 - 1) {                                // (0, kb), 1 <= kb < B/2  <->  (0, B - kb)
+            const int s2 = sc - (ABh - Bi);
+            if (s2 < Bi / 2 - 1) {                               // (0, kb), 1 <= kb < B/2  <->  (0, B - kb)
                 ka = 0;
                 kb = 1 + s2;
-            } else if (s2 < B - 1) {                             // (A/2, kb), kb < B/2  <->  (A/2, B - 1 - kb)
-                ka = A / 2;
-                kb = s2 - (B / 2 - 1);
+            } else if (s2 < Bi - 1) {                            // (A/2, kb), kb < B/2  <->  (A/2, B - 1 - kb)
+                ka = Ai / 2;
+                kb = s2 - (Bi / 2 - 1);
             } else {                                             // the two rows that are their own mirror: side 0 takes (0, 0),
                 ka = 0;                                          // side 1 takes (0, B/2); each is its own partner
                 kb = 0;
                 self = true;
             }
         }
-        const int64_t kam = ka != 0 ? A - ka : 0, kbm = self ? B / 2 : (ka != 0 ? B - 1 - kb : (B - kb) % B);
+        const int kam = ka != 0 ? Ai - ka : 0, kbm = self ? Bi / 2 : (ka != 0 ? Bi - 1 - kb : ((Bi - kb) & (Bi - 1)));
         const int64_t myka = side ? kam : ka, mykb = side ? kbm : kb;
         const bool act = slot_ok;
         cf *row = Tm + (myka * B + mykb) * (int64_t)L;
@@ -755,32 +757,33 @@ __global__ __launch_bounds__(WgCfg<L>::WG) void k_xc_rowsmid(cf *__restrict__ Tm
         int64_t myka, mykb;
         bool act, self;
     };
+    const int Ai = (int)A, Bi = (int)B, lbB = __ffs(Bi) - 1, ABh = (int)(AB / 2);        // (32-bit slot arithmetic with shifts, as above)
     auto decode = [&](int64_t s0) __attribute__((always_inline)) {
-        const int64_t s = s0 + pg;
-        const bool slot_ok = s < nslots;
-        const int64_t sc = slot_ok ? s : 0;
-        int64_t ka, kb;
+        const int s = (int)s0 + pg;
+        const bool slot_ok = s < (int)nslots;
+        const int sc = slot_ok ? s : 0;
+        int ka, kb;
         bool self = false;
-        if (sc < AB / 2 - B) {
-            const int64_t j = B + sc;
-            ka = j / B;
-            kb = j % B;
+        if (sc < ABh - Bi) {
+            const int j = Bi + sc;
+            ka = j >> lbB;
+            kb = j & (Bi - 1);
         } else {
-            const int64_t s2 = sc - (AB / 2 - B);
-            if (s2 < B / 2 - 1) {
+            const int s2 = sc - (ABh - Bi);
+            if (s2 < Bi / 2 - 1) {
                 ka = 0;
                 kb = 1 + s2;
-            } else if (s2 < B - 1) {
-                ka = A / 2;
-                kb = s2 - (B / 2 - 1);
+            } else if (s2 < Bi - 1) {
+                ka = Ai / 2;
+                kb = s2 - (Bi / 2 - 1);
             } else {
                 ka = 0;
                 kb = 0;
                 self = true;
             }
         }
-        const int64_t kam = ka != 0 ? A - ka : 0, kbm = self ? B / 2 : (ka != 0 ? B - 1 - kb : (B - kb) % B);
-        return Slot{side ? kam : ka, side ? kbm : kb, slot_ok, self};
+        const int kam = ka != 0 ? Ai - ka : 0, kbm = self ? Bi / 2 : (ka != 0 ? Bi - 1 - kb : ((Bi - kb) & (Bi - 1)));
+        return Slot{(int64_t)(side ? kam : ka), (int64_t)(side ? kbm : kb), slot_ok, self};
     };
     // the NEXT slot's rows are loaded while this one is transformed (SP_XCROWS_PREFETCH: the loop ran load -> two transforms -> store
     // with two workgroups per CU; no other workgroup writes a slot's rows, so the early read is safe)
