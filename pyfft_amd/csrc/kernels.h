@@ -475,10 +475,11 @@ __global__ __launch_bounds__(WgCfg<L>::WG * WM)
             // kind 1 when the samples end exactly at the middle row (nreal = L/2 * es: a power-of-two ccf): slots t < R/2 are
             // all samples, the others all padding -- no predicates, no 64-bit compares, and the zeros fold into the first butterfly
             const float m1 = (float)ci.mom[0], m2 = (float)ci.mom[1];
+            const int ib = (int)base, ies = (int)es;                 // (32-bit sample indices: at most 2^26 samples per signal)
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
                 if (t < C::R / 2) {
-                    const int64_t i = base + (int64_t)(tid + C::T * t) * es;
+                    const int i = ib + (tid + C::T * t) * ies;
                     v[t] = mk(ci.r1[i] - m1, ci.r2[i] - m2);
                 } else {
                     v[t] = mk(0.f, 0.f);
@@ -908,15 +909,18 @@ __global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
         xf.fwd(v, lds, tid, L);
+        // (32-bit indices: Ltot <= 2^27 here)
+        const int n32 = (int)ro.n, L32 = (int)ro.Ltot;
+        const int jb = 2 * ((int)col + (int)ncols * (int)outer), js = 2 * (int)ncols * (int)nouter;
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
-            const int64_t j2 = 2 * (col + ncols * (outer + nouter * (int64_t)(tid + C::T * t)));
+            const int j2 = jb + js * (tid + C::T * t);
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int64_t i = j2 + e;
+                const int i = j2 + e;
                 const float val = nrm * (e ? -v[t].y : v[t].x);
-                if (i < ro.n) ro.co[i + ro.n - 1] = val;
-                else if (i > ro.Ltot - ro.n) ro.co[i - ro.Ltot + ro.n - 1] = val;
+                if (i < n32) ro.co[i + n32 - 1] = val;
+                else if (i > L32 - n32) ro.co[i - L32 + n32 - 1] = val;
             }
         }
     }
