@@ -516,8 +516,11 @@ __global__ __launch_bounds__(WgCfg<L>::WG * WM)
             }
             __builtin_amdgcn_sched_barrier(0);
         } else {
+            // (32-bit element offsets from the block's base: a column spans less than 2^27 elements)
+            const cf *pin = in + base;
+            const int ies = (int)es;
 #pragma unroll
-            for (int t = 0; t < C::R; ++t) v[t] = in[base + (int64_t)(tid + C::T * t) * es];
+            for (int t = 0; t < C::R; ++t) v[t] = pin[(tid + C::T * t) * ies];
         }
         if (HM && hmask_n > 0) {
             // analytic-signal mask (hilbert.py:63-64) applied while loading the spectrum for the inverse transform
@@ -552,8 +555,12 @@ __global__ __launch_bounds__(WgCfg<L>::WG * WM)
                 v[t] = cmul(v[t], cmul(bt.hi[m >> bt.lb], bt.lo[m & ((1 << bt.lb) - 1)]));
             }
         }
+        {
+            cf *pout = out + base;
+            const int ies = (int)es;
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) out[base + (int64_t)(tid + C::T * t) * es] = v[t];
+            for (int t = 0; t < C::R; ++t) pout[(tid + C::T * t) * ies] = v[t];
+        }
     }
 }
 
@@ -948,10 +955,14 @@ __global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(OU
         const int64_t col = (idx % ncolblocks) * C::FPW + grp;
         const int64_t base = (idx / ncolblocks) * os + col;
         cf v[C::R];
+        {
+            const cf *pin = in + base;
+            const int ies = (int)es;
 #pragma unroll
-        for (int t = 0; t < C::R; ++t) {
-            const cf a = in[base + (int64_t)(tid + C::T * t) * es];
-            v[t] = mk(a.x, -a.y);
+            for (int t = 0; t < C::R; ++t) {
+                const cf a = pin[(tid + C::T * t) * ies];
+                v[t] = mk(a.x, -a.y);
+            }
         }
         const int64_t mc = twmul * col;
         if constexpr (C::R == 16) {
@@ -984,8 +995,10 @@ __global__ __launch_bounds__(WgCfg<L>::WG) __attribute__((amdgpu_waves_per_eu(OU
                 ao[j] = make_float4(ok0 ? x0 : 0.f, scale * v[t].x, ok1 ? x1 : 0.f, -scale * v[t].y);
             }
         } else {
+            cf *pout = out + base;
+            const int ies = (int)es;
 #pragma unroll
-            for (int t = 0; t < C::R; ++t) out[base + (int64_t)(tid + C::T * t) * es] = mk(scale * v[t].x, -scale * v[t].y);
+            for (int t = 0; t < C::R; ++t) pout[(tid + C::T * t) * ies] = mk(scale * v[t].x, -scale * v[t].y);
         }
     }
 }
