@@ -132,7 +132,10 @@ int sp_welch_apply(const double *state, const float *win, int nfft, int64_t fram
  *      it is reported.  K submits + one flush = K Welch PSDs; no host synchronisation.  frames_total = frames of the WHOLE
  *      stream (the normalisation); nmean = this shard's own samples (halo excluded).  sp_welch_psd_dist = submit + flush.
  *      Shapes: as sp_welch_export.  Reference path: the same as sp_welch_psd (fft_analysis.py:2126-2203, :1944-1990) over
- *      segments dealt out to the ranks. */
+ *      segments dealt out to the ranks.
+ *      With a communicator of more than one rank the library asks RCCL for at most 4 workgroups per collective
+ *      (ncclCommInitRankConfig; SP_DIST_RCCL_CTAS) and partitions its main kernels over all but 8 CUs (SP_DIST_RESERVE_CUS), so
+ *      that RCCL's kernel -- which cannot share a CU with the main kernel -- runs beside it instead of delaying the next one. */
 #define SP_COMM_ID_BYTES 128
 int sp_comm_unique_id(void *id_out /* SP_COMM_ID_BYTES */);
 int sp_comm_init(const void *id, int world, int rank);
