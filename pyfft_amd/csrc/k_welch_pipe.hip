@@ -609,8 +609,12 @@ int launch_welch_pipe(LaunchCtx c, const void *x, bool cplx, const float *win, i
                 return -1;                                                                            \
             once = true;                                                                              \
         }                                                                                             \
-        hipLaunchKernelGGL((k_welch_pipe<CP, S, OP>), dim3(rp.blocks, gy), dim3(768), lds, c.stream, x, win, nframes, rp.fpg, trend, \
-                           xf.tb, partial, spartial, x_cs, gpr);                                      \
+        if (c.stop)                                                                                   \
+            hipExtLaunchKernelGGL((k_welch_pipe<CP, S, OP>), dim3(rp.blocks, gy), dim3(768), lds, c.stream, nullptr, c.stop, 0, x, win, \
+                                  nframes, rp.fpg, trend, xf.tb, partial, spartial, x_cs, gpr);       \
+        else                                                                                          \
+            hipLaunchKernelGGL((k_welch_pipe<CP, S, OP>), dim3(rp.blocks, gy), dim3(768), lds, c.stream, x, win, nframes, rp.fpg, trend, \
+                               xf.tb, partial, spartial, x_cs, gpr);                                  \
     }
     const int shift = hop / 256;
     const unsigned gy = mode == 5 ? (unsigned)nch : 1u;

@@ -3,12 +3,17 @@
 #include <stdlib.h>
 #include "kernels.h"
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace sp {
 
 struct LaunchCtx {
     hipStream_t stream;
     int ncu;
+    // optional: recorded as the launch's own completion signal (hipExtLaunchKernelGGL) by the launchers that honour it
+    // (launch_welch_pipe) -- a hipEventRecord behind the kernel is a packet of its own and costs the next launch on the
+    // stream 3-5 us (tools/ubench/coexec_rccl.hip)
+    hipEvent_t stop = nullptr;
 };
 
 // transform selection for a length n: pow2 workgroup FFT, or Bluestein on an L-point one

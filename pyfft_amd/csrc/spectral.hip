@@ -850,9 +850,13 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
         HIPCHK(hipEventRecord(sl->ev_in, g.stream));
         HIPCHK(hipStreamWaitEvent(sl->main, sl->ev_in, 0));
     }
+    // (streaming engine: the main kernel's event as the launch's own completion signal, not a record behind it)
+    const bool stop_ev = sl && pipe && !g.profile && !env_flag("SP_DIST_RECORD_EVENT");
     if (pipe) {
         ProfScope ps(mc.stream);
-        LAUNCHCHK(launch_welch_pipe(mc, xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, spartial,
+        LaunchCtx mcs = mc;
+        if (stop_ev) mcs.stop = sl->ev_main;
+        LAUNCHCHK(launch_welch_pipe(mcs, xd, cplx, (const float *)win_d, hop, nframes, tb.f, xf, partial, rp, spartial,
                                     realpair ? 3 : (lobesum ? 9 : 0)));
         g.last_kernel = realpair ? "k_welch_pipe(onepass,realpair)" : (lobesum ? "k_welch_pipe(onepass,lobesum)" : "k_welch_pipe(onepass)");
     } else {
@@ -864,7 +868,7 @@ int welch_accum_locked(const void *xd, bool cplx, int64_t nsig, const float *win
     // the epilogue's launch context: the launch stream, or the engine's epilogue stream behind the main kernel's event
     LaunchCtx ec = lc();
     if (sl) {
-        HIPCHK(hipEventRecord(sl->ev_main, mc.stream));
+        if (!stop_ev) HIPCHK(hipEventRecord(sl->ev_main, mc.stream));
         HIPCHK(hipStreamWaitEvent(sl->epi, sl->ev_main, 0));
         ec = LaunchCtx{sl->epi, g.ncu};
     }
@@ -1596,6 +1600,9 @@ int sp_welch_dist_submit(const void *x, int x_dtype, int64_t nsig, const float *
     // the main kernel just enqueued).  That makes valid, in stream order: without communicator the output of step k - 1; with
     // one the output of step k - 2 (applied by step k - 1's epilogue launch).
     if (prv.busy) {
+        // (this wait is a packet of its own between two main kernels: ~4 us per step, measured by leaving it out -- 0.0826 ->
+        //  0.0784 ms at 2^25 samples.  It is what orders the scratch reuse and validates outputs in stream order; waiting only every
+        //  few steps over more scratch sets would save most of it at the price of results arriving in batches: not done)
         HIPCHK(hipStreamWaitEvent(g.stream, geng.ev_epi[o], 0));
         if (!comm) {
             prv.busy = false;
