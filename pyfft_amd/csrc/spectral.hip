@@ -977,7 +977,10 @@ static int dist_reserved_cus() {
     }
     // (twice the workgroup limit, at least 8: a limit RCCL rounds up must still find room; 8 CUs cost 1.2-1.5 % of the main
     //  kernel, tools/reserve_ab.sh: 0.5495 -> 0.5550 / 0.5580 ms at 2^28 samples for 4 / 8, 0.0819 -> 0.0825 / 0.0829 at 2^25)
-    return (gcomm.comm && gcomm.world > 1) ? (2 * gcomm.ctas > 8 ? 2 * gcomm.ctas : 8) : 0;
+    //  A multiple of 8 = one CU on every XCD: workgroups are dealt to the XCDs in turn, a reserve of 4 leaves XCDs 0-3 full --
+    //  exactly where the collective's first workgroups go (tools/ubench/coexec_rccl.hip))
+    const int want = 2 * gcomm.ctas > 8 ? 2 * gcomm.ctas : 8;
+    return (gcomm.comm && gcomm.world > 1) ? (want + 7) / 8 * 8 : 0;
 }
 
 // ---- the streaming engine behind sp_welch_dist_submit / _flush ------------------------------------------------------------
