@@ -305,7 +305,10 @@ def main():
                              "samples on every rank",
                    "parallelism": "segment-sharded x%d, one RCCL all-reduce of the shard state (%d doubles) per step, "
                                   "overlapped with the next step's kernels; %s" % (world, 5 * nfft + 8,
-                                  "issued by libspectral on its own stream (sp_welch_dist_submit)" if native else
+                                  "issued by libspectral on its own stream (sp_welch_dist_submit; communicator limited to "
+                                  "%s workgroups, main kernels over all but %s CUs so that RCCL's kernel runs beside them)"
+                                  % (os.environ.get("SP_DIST_RCCL_CTAS", "4"),
+                                     os.environ.get("SP_DIST_RESERVE_CUS", "8" if world > 1 else "0")) if native else
                                   "issued through torch.distributed (WelchPipeline)")
                                   if collective else ("single GPU, no collective; steps streamed through sp_welch_dist_submit (the "
                                   "epilogue of step k runs beside the main kernel of step k+1; K submits + the flush are inside "
