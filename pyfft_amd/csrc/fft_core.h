@@ -691,8 +691,16 @@ template <int N, bool TW1LDS = false, bool RM = false> struct WgFft {
 
     // v[t] <-> element tid + T*t on entry and exit.  lds0/lds1: two exchange images (may be equal,
     // SINGLE=true, then a barrier also precedes every write).
-    template <bool SINGLE> __device__ __forceinline__ void run(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
-        pass<0, SINGLE>(v, lds0, lds1, tid);
+    // WL (wave-local): the T threads of a transform are lanes of ONE wave (T <= 64, row-mapped kernels: thread % T): the
+    // exchange needs no workgroup barrier -- LDS operations of a wave execute in order, so its gather sees its scatter -- and
+    // the workgroup's other transforms (other waves) are not held up at an s_barrier for it
+    template <bool SINGLE, bool WL = false> __device__ __forceinline__ void run(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
+        static_assert(!WL || T <= 64, "wave-local exchange: one wave holds the whole transform");
+        pass<0, SINGLE, WL>(v, lds0, lds1, tid);
+    }
+    template <bool WL> static __device__ __forceinline__ void xsync() {
+        if constexpr (WL) __builtin_amdgcn_wave_barrier();
+        else __syncthreads();
     }
 
     // butterflies of pass P with the Stockham scatter folded in (radix 16, one butterfly per thread, scalar form)
@@ -752,25 +760,25 @@ template <int N, bool TW1LDS = false, bool RM = false> struct WgFft {
         dft16s_es_win(v, w, store);
     }
 
-    template <int P, bool SINGLE> __device__ __forceinline__ void pass(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
+    template <int P, bool SINGLE, bool WL = false> __device__ __forceinline__ void pass(cf (&v)[R], cf *lds0, cf *lds1, int tid) const {
         constexpr bool LAST = (P == NP - 1);
         cf *lds = (P & 1) ? lds1 : lds0;
         if constexpr (SP_EARLY_SCATTER && !SP_PACKED && !SP_ABLATE && !SINGLE && !LAST && PL::radix(P) == 16 && R == 16) {
             bfly_scatter<P>(v, lds, tid);
-            __syncthreads();
+            xsync<WL>();
             gather<P>(v, lds, tid);
-            pass<P + 1, SINGLE>(v, lds0, lds1, tid);
+            pass<P + 1, SINGLE, WL>(v, lds0, lds1, tid);
             return;
         }
-        if constexpr (!LAST && SINGLE && !(SP_ABLATE & 2)) __syncthreads();   // previous readers of this image are done
+        if constexpr (!LAST && SINGLE && !(SP_ABLATE & 2)) xsync<WL>();       // previous readers of this image are done
         bfly<P>(v, tid);
         if constexpr (!LAST && (SP_ABLATE & 2)) {
-            pass<P + 1, SINGLE>(v, lds0, lds1, tid);
+            pass<P + 1, SINGLE, WL>(v, lds0, lds1, tid);
         } else if constexpr (!LAST) {
             scatter<P>(v, lds, tid);
-            __syncthreads();
+            xsync<WL>();
             gather<P>(v, lds, tid);
-            pass<P + 1, SINGLE>(v, lds0, lds1, tid);
+            pass<P + 1, SINGLE, WL>(v, lds0, lds1, tid);
         }
     }
 };

@@ -18,6 +18,10 @@
 
 namespace sp {
 
+// SP_CARRY_WAVELOCAL=1: k_welch_carry at <= 1024 points exchanges without workgroup barriers (one wave holds a whole transform)
+#ifndef SP_CARRY_WAVELOCAL
+#define SP_CARRY_WAVELOCAL 1
+#endif
 template <int L> struct WgCfg {
     using PL = FftPlan<L>;
     static constexpr int R = PL::R, T = PL::T;
@@ -50,7 +54,25 @@ template <int N, bool TW1LDS = false> struct XfPow2 {
     __device__ __forceinline__ void fwd(cf (&v)[C::R], cf *lds, int tid, int) const { f.template run<true>(v, lds, lds, tid); }
     // two exchange images (ping-pong): one barrier per exchange instead of two
     __device__ __forceinline__ void fwd2(cf (&v)[C::R], cf *lds_a, cf *lds_b, int tid) const { f.template run<false>(v, lds_a, lds_b, tid); }
+    // fwd without workgroup barriers, for row-mapped kernels whose transform sits in one wave (T <= 64; fft_core.h, WL)
+    __device__ __forceinline__ void fwdw(cf (&v)[C::R], cf *lds, int tid, int) const { f.template run<true, true>(v, lds, lds, tid); }
 };
+
+// forward transform of a ROW-MAPPED kernel (SP_KERNEL_PROLOGUE: thread % T within a group of T consecutive threads): power-of-two
+// transforms whose T threads are lanes of one wave exchange without workgroup barriers (SP_ROW_WAVELOCAL; fft_core.h, WL) -- the
+// group's image is private to it, and the other groups of the workgroup (other waves) are not held up at an s_barrier
+#ifndef SP_ROW_WAVELOCAL
+#define SP_ROW_WAVELOCAL 1
+#endif
+template <class X, int R_> __device__ __forceinline__ void fwd_row(const X &xf, cf (&v)[R_], cf *lds, int tid, int n) {
+    if constexpr (X::EXACT && SP_ROW_WAVELOCAL) {
+        if constexpr (X::C::T <= 64 && X::C::FPW > 1) {
+            xf.fwdw(v, lds, tid, n);
+            return;
+        }
+    }
+    xf.fwd(v, lds, tid, n);
+}
 
 template <int L_> struct XfBlue {
     static constexpr int L = L_;
@@ -319,7 +341,7 @@ __global__ __launch_bounds__(X::C::WG) void k_fft_c2c(const cf *__restrict__ in,
         }
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = mk(v[t].x, sgn * v[t].y);
-        xf.fwd(v, lds, tid, n);
+        fwd_row(xf, v, lds, tid, n);
         if (bt.lo != nullptr) {
             const int64_t rowm = bt.mod > 0 ? bl % bt.mod : bl;
 #if SP_BIGTW_REC
@@ -1039,7 +1061,7 @@ __global__ __launch_bounds__(X::C::WG) void k_welch(const void *__restrict__ x, 
         if (segmean) segment_detrend<C>(v, lds, tid, n, X::EXACT, segmean);   // per-segment (mlab) detrend; uniform
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = w[t] * detrended<LIN>(v[t], tr, base + tid + C::T * t);
-        xf.fwd(v, lds, tid, n);
+        fwd_row(xf, v, lds, tid, n);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) acc[t] += keep * cnorm(v[t]);
     }
@@ -1091,7 +1113,7 @@ __device__ __forceinline__ void welch_rp_body(const float *__restrict__ x, const
             const cf b = detrended<LIN>(mk(v[t].y, 0.f), tr, base_b + j);
             v[t] = mk(w[t] * a.x, kb * w[t] * b.x);
         }
-        xf.fwd(v, lds, tid, n);
+        fwd_row(xf, v, lds, tid, n);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) acc[t] += keep * cnorm(v[t]);
     }
@@ -1333,7 +1355,8 @@ __device__ __forceinline__ void welch_carry_body(
             const bool swap = ((C::PL::NP - 1) & 1) && (i & 1);
             xf.fwd2(v, swap ? lds_b : lds, swap ? lds : lds_b, tid);
         } else {
-            xf.fwd(v, lds, tid, N);
+            if constexpr (SP_CARRY_WAVELOCAL && C::T <= 64 && C::FPW > 1) xf.fwdw(v, lds, tid, N);
+            else xf.fwd(v, lds, tid, N);
         }
         if constexpr (COG) {
             // every bin (Doppler.cog's form; a band limit goes through the generic kernel): with ks = tid + c_t,
@@ -1872,8 +1895,8 @@ __global__ __launch_bounds__(X::C::WG) void k_welch_csd(const void *__restrict__
             vx[t] = w[t] * detrended<LIN>(vx[t], trx, idx);
             vy[t] = w[t] * detrended<LIN>(vy[t], try_, idx);
         }
-        xf.fwd(vx, lds, tid, n);
-        xf.fwd(vy, lds, tid, n);
+        fwd_row(xf, vx, lds, tid, n);
+        fwd_row(xf, vy, lds, tid, n);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             axx[t] += keep * cnorm(vx[t]);
@@ -1939,7 +1962,7 @@ __global__ __launch_bounds__(WgCfg<N>::WG) void k_welch_csd_rp(const float *__re
             const cf b = detrended<LIN>(mk(v[t].y, 0.f), try_, idx);
             v[t] = mk(w[t] * a.x, w[t] * b.x);
         }
-        xf.fwd(v, lds, tid, N);
+        fwd_row(xf, v, lds, tid, N);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < C::R; ++t) lds[tid + C::T * t] = v[t];
@@ -2334,7 +2357,7 @@ __global__ __launch_bounds__(X::C::WG) void k_stft(const void *__restrict__ x, c
             pw = group_lane_sum<W>(pw);
             if (act && (tid & (W - 1)) == 0) atomicAdd(&pseg[g], (double)pw);
         }
-        xf.fwd(v, lds, tid, n);
+        fwd_row(xf, v, lds, tid, n);
         if (cog != nullptr) {
             // centre of gravity of the frame's two-sided power spectrum (Doppler.py:43-58): moments sum |X|^2 ks and
             // sum |X|^2 over the signed bin index ks = fftfreq(n) n, band klo <= |ks| <= khi; the caller divides
@@ -2985,7 +3008,7 @@ __global__ __launch_bounds__(WgCfg<N>::WG) __attribute__((amdgpu_waves_per_eu((F
                 if (has_b) atomicAdd(&pseg[ga + 1], (double)pwb);
             }
         }
-        xf.fwd(v, lds, tid, N);
+        fwd_row(xf, v, lds, tid, N);
         // mirror exchange
         __syncthreads();
 #pragma unroll
@@ -3694,7 +3717,7 @@ __global__ __launch_bounds__(X::C::WG)
             const float a = x[bl * x_ld + (j < n_in ? j : n_in - 1)];     // clamped, unconditional
             v[t] = mk(j < n_in ? a : 0.f, 0.f);
         }
-        xf.fwd(v, lds, tid, n);
+        fwd_row(xf, v, lds, tid, n);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) {
             const int k = tid + C::T * t;
@@ -3707,7 +3730,7 @@ __global__ __launch_bounds__(X::C::WG)
                 v[t] = mk(h * v[t].x, -h * v[t].y);      // mask, then conj for the inverse
             }
         }
-        xf.fwd(v, lds, tid, n);
+        fwd_row(xf, v, lds, tid, n);
         if (act) {
 #pragma unroll
             for (int t = 0; t < C::R; ++t) {
@@ -3790,10 +3813,10 @@ __global__ __launch_bounds__(WgCfg<N>::WG)
         cf H[C::R];
 #pragma unroll
         for (int t = 0; t < C::R; ++t) H[t] = Hs[hoff + tid + C::T * t];
-        xf.fwd(v, lds, tid, N);
+        fwd_row(xf, v, lds, tid, N);
 #pragma unroll
         for (int t = 0; t < C::R; ++t) v[t] = cconj(cmul(v[t], H[t]));
-        xf.fwd(v, lds, tid, N);
+        fwd_row(xf, v, lds, tid, N);
         if (act) {
             if constexpr (!EDGE) {
                 float *y0 = y + s0;
